@@ -1,0 +1,138 @@
+"""Pins oracle/np_oracle.py against golden vectors produced by the imported reference
+(oracle/make_fixtures.py).  CPU only.  Tolerances: the reference computes in fp32, the
+oracle here runs in fp64, so differences are fp32 rounding of the reference itself:
+rtol 2e-4 / atol 2e-5 on activations and grads, rtol 1e-5 on the sum-reduced losses."""
+import numpy as np
+import pytest
+
+import np_oracle as O
+from golden_util import load, expect, has
+
+F64 = np.float64
+
+# A Linear bias that feeds BatchNorm has an analytically ZERO gradient (BN subtracts the
+# batch mean).  The reference holds fp32 rounding noise (~1e-8) there and Adam normalises
+# it to +-lr steps, so these three tensors -- and the running_mean that absorbs them --
+# follow rounding noise, not mathematics.  They do not change the training-mode function.
+CHAOTIC_BIASES = ("encoder_a.fc.0.bias", "encoder_b.fc.0.bias", "encoder_b.fc.4.bias")
+
+
+def _run_mm(name):
+    fx = load(name)
+    A, D, S, L, E = [int(x) for x in fx["dims"]]
+    B, seed, n_steps = int(fx["B"]), int(fx["seed"]), int(fx["n_steps"])
+    beta, gamma = float(fx["beta"]), float(fx["gamma"])
+    cw = fx["class_weights"].astype(F64) if "class_weights" in fx.files else None
+    P, Bf = O.make_params(seed, A, D, S, L, E)
+    P, Bf = O.cast_tree(P, F64), O.cast_tree(Bf, F64)
+    a, b, site = O.make_batch(seed + 1, B, A, D, S)
+    np.testing.assert_array_equal(a, fx["a"]); np.testing.assert_array_equal(b, fx["b"])
+    np.testing.assert_array_equal(site, fx["site"])
+    a, b = a.astype(F64), b.astype(F64)
+    state, step = O.adamw_init(P)
+    for s in range(n_steps):
+        masks, eps = O.make_noise(seed + 100 + s, B, L)
+        r = O.train_step(P, Bf, state, step, a, b, site, masks, eps.astype(F64), beta, gamma, cw,
+                         lr=float(fx["lr"]), wd=float(fx["wd"]))
+        step = r["step"]
+        pre = f"s{s}."
+        if s == 0:
+            for k in ("out_a", "out_b", "out_c", "mu", "logvar"):
+                expect(fx, pre + k, r[k], 2e-4, 2e-5)
+        np.testing.assert_allclose([r["total"], r["recon"], r["cls"], r["kld"]], fx[pre + "loss"], rtol=1e-5)
+        if s in (0, n_steps - 1):
+            for k, g in r["grads"].items():
+                # grads of a Linear bias feeding BatchNorm are exactly 0 analytically; the
+                # reference holds fp32 noise there, hence the absolute tolerance.
+                expect(fx, pre + "grad." + k, g, 2e-3, 2e-4, scale_atol=3e-4)
+    for k, v in list(P.items()) + list(Bf.items()):
+        if k in CHAOTIC_BIASES:
+            continue
+        expect(fx, "final." + k, v, 1e-4, 3e-4 if k.endswith("running_mean") else 2e-6,
+               outlier_frac=2e-3, outlier_atol=1.1 * 5e-4 * n_steps)
+    # adopt the reference's values for the chaotic tensors so the eval check stays tight
+    for k in CHAOTIC_BIASES:
+        P[k] = fx["final." + k].astype(F64)
+    for k in Bf:
+        if k.endswith("running_mean"):
+            Bf[k] = fx["final." + k].astype(F64)
+    # eval forward, all modalities and subsets (vae.py:65-71)
+    _, eps = O.make_noise(seed + 900, B, L)
+    eps = eps.astype(F64)
+    for tag, kw in (("", dict(a=a, b=b, site=site)), ("only_a.", dict(a=a)), ("only_b.", dict(b=b)),
+                    ("only_site.", dict(site=site)), ("a_site.", dict(a=a, site=site))):
+        oa, ob, oc, mu, lv, _ = O.vae_forward(P, Bf, eps=eps, train=False, **kw)
+        for nm, t in zip(["out_a", "out_b", "out_c", "mu", "logvar"], [oa, ob, oc, mu, lv]):
+            expect(fx, f"eval.{tag}{nm}", t, 5e-4, 1e-4)
+
+
+@pytest.mark.parametrize("name", ["mm_tiny_b16", "mm_default_b32", "mm_default_b77_w"])
+def test_multimodal_train_steps(name):
+    _run_mm(name)
+
+
+@pytest.mark.parametrize("kind", ["rna2dna", "dna2rna"])
+def test_directional(kind):
+    fx = load(kind + "_b32")
+    A, D, S, L, E = [int(x) for x in fx["dims"]]
+    B, seed, beta = int(fx["B"]), int(fx["seed"]), float(fx["beta"])
+    P, Bf = O.make_params(seed, A, D, S, L, E)
+    P, Bf = O.cast_tree(P, F64), O.cast_tree(Bf, F64)
+    a, b, site = O.make_batch(seed + 1, B, A, D, S)
+    a, b = a.astype(F64), b.astype(F64)
+    masks, eps = O.make_noise(seed + 100, B, L)
+    eps = eps.astype(F64)
+    ren = O.directional_param_names(kind, A, D, S, L, E)
+    x, tgt = (a, b) if kind == "rna2dna" else (b, a)
+    out, mu, lv, cache = O.directional_forward(kind, P, Bf, x, site, masks, eps, True)
+    lossf = O.rna2dna_loss if kind == "rna2dna" else O.dna2rna_loss
+    total, rec, kld, g = lossf(out, tgt, mu, lv, beta)
+    expect(fx, "s0.out", out, 2e-4, 2e-5); expect(fx, "s0.mu", mu, 2e-4, 2e-5)
+    expect(fx, "s0.logvar", lv, 2e-4, 2e-5)
+    np.testing.assert_allclose([total, rec, kld], fx["s0.loss"], rtol=1e-5)
+    G = O.directional_backward(P, cache, g["recon"], g["mu"], g["logvar"])
+    sub = {k: v for k, v in P.items() if k.split(".", 1)[0] in ren}
+    assert set(G) == set(sub)
+    for k, gv in G.items():
+        top, rest = k.split(".", 1)
+        expect(fx, f"s0.grad.{ren[top]}.{rest}", gv, 2e-3, 2e-4, scale_atol=3e-4)
+    state, step = O.adamw_init(sub)
+    O.adamw_step(sub, G, state, step)
+    for k, v in sub.items():
+        top, rest = k.split(".", 1)
+        if k in CHAOTIC_BIASES:
+            sub[k] = fx[f"final.{ren[top]}.{rest}"].astype(F64)
+            continue
+        expect(fx, f"final.{ren[top]}.{rest}", v, 1e-4, 2e-6, outlier_frac=2e-3, outlier_atol=1.1 * 5e-4)
+    for k in Bf:
+        top, rest = k.split(".", 1)
+        if k.endswith("running_mean") and top in ren:
+            Bf[k] = fx[f"final.{ren[top]}.{rest}"].astype(F64)
+    out, mu, lv, _ = O.directional_forward(kind, sub, Bf, x, None, None, eps, False)
+    expect(fx, "eval.nosite.out", out, 5e-4, 1e-4); expect(fx, "eval.nosite.mu", mu, 5e-4, 1e-4)
+
+
+def test_loss_edges():
+    fx = load("loss_edges")
+    args = [fx[k].astype(F64) if fx[k].dtype != np.int64 else fx[k]
+            for k in ("recon_a", "a", "recon_b", "b", "recon_c", "site", "mu", "logvar")]
+    for tag, cw in (("now", None), ("w", fx["w"].astype(F64))):
+        total, rec, cls, kld, g = O.vae_loss(*args, beta=0.25, gamma=0.7, class_weights=cw)
+        np.testing.assert_allclose([total, rec, cls, kld], fx[tag + ".loss"], rtol=2e-6)
+        for nm in ("recon_a", "recon_c", "mu", "logvar"):
+            np.testing.assert_allclose(g[nm], fx[f"{tag}.grad.{nm}"], rtol=1e-5, atol=1e-6)
+        # saturated BCE entries: torch's backward divides by max(p(1-p), 1e-12)
+        np.testing.assert_allclose(g["recon_b"], fx[f"{tag}.grad.recon_b"], rtol=1e-5, atol=1e-6)
+
+
+def test_batchnorm_needs_two_rows():
+    P, Bf = O.make_params(1, 8, 8, 3, 2, 4)
+    a, b, site = O.make_batch(2, 1, 8, 8, 3)
+    masks, eps = O.make_noise(3, 1, 2)
+    with pytest.raises(ValueError):
+        O.vae_forward(P, Bf, a, b, site, masks, eps, True)
+
+
+def test_no_modalities_returns_nones():
+    P, Bf = O.make_params(1, 8, 8, 3, 2, 4)
+    assert O.vae_forward(P, Bf) == (None,) * 6
