@@ -1,0 +1,228 @@
+/* mmvae_hip.h -- C ABI of libmmvae_hip.so: the MI355X (gfx950) kernels behind the
+ * MultiModalVAE training hot path of marcin119a/vae-los-angeles.
+ *
+ * The reference has no FFI of its own: its "operator interface" for this path is the set of
+ * stock PyTorch ops its modules call.  Each entry point below names the reference call sites
+ * (file:line, relative to the reference repo) whose device work it replaces.  The host side
+ * (the mmvae Python package under vae-los-angeles_amd/) binds these with ctypes and keeps the reference's
+ * src.models / src.utils.losses class surface on top.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory and sizes; no framework types.  The library never
+ *     allocates or frees device memory and keeps no state between calls.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); nothing
+ *     synchronises, so calls are graph-capturable.
+ *   - return value: 0 = ok; <0 = argument check failed (MMVAE_ERR_*); >0 = hipError_t of the launch.
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ *   - "activation type" = float in MMVAE_PREC_F32 mode, bfloat16 in MMVAE_PREC_BF16 mode.
+ */
+#ifndef MMVAE_HIP_H
+#define MMVAE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMVAE_OK 0
+#define MMVAE_ERR_ARG (-1)
+#define MMVAE_ERR_DTYPE (-2)
+
+enum { MMVAE_F32 = 0, MMVAE_BF16 = 1 };                 /* storage dtype of a buffer   */
+enum { MMVAE_PREC_F32 = 0, MMVAE_PREC_BF16 = 1 };       /* MFMA operand precision      */
+enum { MMVAE_PRO_NONE = 0, MMVAE_PRO_BN_RELU_DROP = 1 };
+enum { MMVAE_EPI_STORE = 0, MMVAE_EPI_RELU_MASK = 1, MMVAE_EPI_BN_BWD = 2 };
+enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
+
+#define MMVAE_TILE 128          /* GEMM output tile edge; BN partial sums have one row per 128 rows */
+
+int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight preparation: fp32 master weights -> zero-padded MFMA operand copies (compute type),
+ * plain and transposed, plus concatenations (fc_mu|fc_logvar heads).  One launch for a whole
+ * table of items held in device memory.
+ *   dst[r][c] (r < dst_rows, c < dst_cols, leading dim dst_ld) =
+ *       transpose ? src[c][r] : src[r][c]   if inside src's logical [src_rows][src_cols], else 0
+ * Replaces: the implicit weight reads of every aten::addmm / mm on the path.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* src; void* dst;
+    int32_t src_rows, src_cols; int64_t src_ld;
+    int32_t dst_rows, dst_cols; int64_t dst_ld;
+    int32_t transpose; int32_t dst_dtype;
+} mmvae_prep_item;
+int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( prologue(A)[M,K] x W[N,K]^T )          (gemm_nt.hip)
+ *   W        prepared operand [ceil128(N)][ceil64(K)] in compute type, ldw % 64 == 0
+ *   prologue MMVAE_PRO_BN_RELU_DROP: A is the previous layer's PRE-BatchNorm output (activation
+ *            type); the kernel applies relu(A*pro_scale[k]+pro_shift[k]) * keep/(1-p) on the fly
+ *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask] or NULL.
+ *   epilogue MMVAE_EPI_STORE    : C = act(acc + bias) (+ C if accumulate); optional per-column
+ *                                 (sum, sum of squares) partials per 128-row tile for BatchNorm
+ *            MMVAE_EPI_RELU_MASK: C = acc * (h > 0)                (ReLU backward, decoders)
+ *            MMVAE_EPI_BN_BWD   : C = acc * keep/(1-p) * (h*bn_scale+bn_shift > 0), partials
+ *                                 (sum C, sum C*xhat)  (Dropout+ReLU backward and the two
+ *                                 BatchNorm backward reductions; h = pre-BN output)
+ * Replaces: nn.Linear forward = aten::addmm (encoders.py:13,18-19,31,35,40-41,54-55;
+ *   decoders.py:13,15,27,29,31,44,46), relu/sigmoid (decoders.py:14,28,30,32), batch-norm
+ *   statistics, and the dX mm of each Linear backward (optimize_hyperparameters.py:112).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t prec, M, N, K;
+    const void* a; int32_t a_dtype; int64_t lda;
+    int32_t prologue;
+    const float* pro_scale; const float* pro_shift; const uint8_t* pro_mask; int64_t ld_pro_mask; float pro_inv_keep;
+    const void* w; int64_t ldw;
+    int32_t epilogue;
+    void* c; int32_t c_dtype; int64_t ldc;
+    const float* bias; int32_t act; int32_t accumulate;
+    const void* h; int64_t ldh;
+    const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;
+    const uint8_t* epi_mask; int64_t ld_epi_mask; float epi_inv_keep;
+    float* part1; float* part2; int64_t ldp;
+} mmvae_gemm_nt_args;
+int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * dW[N,K] += P[M,N]^T x Q[M,K] ;  db[N] += column sums of P      (gemm_tn.hip)
+ *   P = gradient w.r.t. the layer output, Q = the layer input (optionally through the same
+ *   BN+ReLU+Dropout prologue as above).  dW/db are fp32 and ACCUMULATED with atomics: zero them
+ *   first.  nsplit <= 0 lets the library choose the batch split.
+ * Replaces: the dW mm and db sum of each Linear backward (optimize_hyperparameters.py:112).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t prec, M, N, K;
+    const void* p; int32_t p_dtype; int64_t ldp;
+    const void* q; int32_t q_dtype; int64_t ldq;
+    int32_t q_prologue;
+    const float* pro_scale; const float* pro_shift; const uint8_t* pro_mask; int64_t ld_pro_mask; float pro_inv_keep;
+    float* dw; int64_t lddw; float* db;
+    int32_t nsplit;
+} mmvae_gemm_tn_args;
+int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d, training mode (encoders.py:14,32,36): reduce the per-tile partials to
+ * mean / biased var, emit scale = gamma*rstd and shift = beta - mean*scale for the consumer's
+ * prologue, save mean/rstd for backward, update running stats (momentum, UNBIASED variance)
+ * and num_batches_tracked.  Eval mode: coefficients from the running stats.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, N, n_tiles; const float* part_sum; const float* part_sumsq; int64_t ldp;
+    const float* gamma; const float* beta; float eps; float momentum;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* may be NULL */
+    float* mean; float* rstd; float* scale; float* shift;
+} mmvae_bn_finalize_args;
+int mmvae_bn_finalize(const mmvae_bn_finalize_args* args, void* stream);
+int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, void* stream);
+
+/* BatchNorm backward, second half: from the partials (sum d, sum d*xhat) of MMVAE_EPI_BN_BWD:
+ *   dgamma += sum d*xhat ; dbeta += sum d ; coef = {gamma*rstd, dbeta/M, dgamma/M}
+ * and then   dy = coef0 * (d - coef1 - xhat*coef2)   in place on the activation-typed buffer d. */
+typedef struct {
+    int32_t M, N, n_tiles; const float* part_d; const float* part_dx; int64_t ldp;
+    const float* gamma; const float* rstd;
+    float* dgamma; float* dbeta; float* coef;           /* coef: [3][N] */
+} mmvae_bn_bwd_finalize_args;
+int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* args, void* stream);
+int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                       const float* mean, const float* rstd, const float* coef, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EncoderC (encoders.py:57-61): Embedding + two heads == a per-class table
+ *   T[S][2L] = emb[S][E] x [Wmu;Wlv]^T + [bmu;blv]      (fp32), gathered per sample later.
+ * Backward: from dT[S][2L]: dEmb, dWmu, dWlv, dbmu, dblv (all accumulated).
+ * ------------------------------------------------------------------------------------------- */
+int mmvae_embed_table_fwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* b_mu,
+                          const float* w_lv, const float* b_lv, float* table, void* stream);
+int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* w_lv,
+                          const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
+                          float* d_b_lv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mean-fusion over the modalities present + reparameterisation (vae.py:65-73, 11-15):
+ *   mu = mean_m mu_m ; logvar = mean_m logvar_m ; z = mu + eps * exp(0.5*logvar)
+ *   heads_x: [B][2L] fp32 (mu | logvar) or NULL; table/site: EncoderC table + int64 labels or NULL.
+ *   z is written in activation type with leading dim ldz (pad columns are zeroed).
+ * Backward: d_heads[B][2L] = [ (g_mu + dz)/n | (g_lv + dz*eps*std/2)/n ], and the same rows
+ *   scatter-added into d_table[site] when the site modality is present.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, L, n_mod;
+    const float* heads_a; const float* heads_b; int64_t ld_heads;
+    const float* table; const int64_t* site; int32_t S;
+    const float* eps;
+    float* mu; float* logvar;
+    void* z; int32_t z_dtype; int64_t ldz;
+} mmvae_fuse_fwd_args;
+int mmvae_fuse_reparam_fwd(const mmvae_fuse_fwd_args* args, void* stream);
+
+typedef struct {
+    int32_t B, L, n_mod;
+    const float* g_mu; const float* g_lv;           /* may be NULL (treated as 0) */
+    const float* dz; int64_t lddz;
+    const float* eps; const float* logvar;
+    float* d_heads; int64_t ld_heads;
+    float* d_table; const int64_t* site; int32_t S;  /* may be NULL */
+} mmvae_fuse_bwd_args;
+int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * vae_loss (src/utils/losses.py:8-46) and the directional losses
+ * (src/utils/directional_losses.py:8-55), one pass, optional terms (NULL pointers skip a term):
+ *   sums[0] += sum (recon_a-a)^2                               (losses.py:31)
+ *   sums[1] += sum -[b*max(log p,-100) + (1-b)*max(log(1-p),-100)]   (losses.py:34)
+ *   sums[2] += sum_i w[site_i] * nll_i                          (losses.py:39)
+ *   sums[3] += -0.5 * sum(1 + lv - mu^2 - exp(lv))              (losses.py:42)
+ * `sums` is double[4], zeroed by the caller.  Gradients of total = s0+s1+gamma*s2+beta*s3:
+ *   g_a = 2(recon_a-a) ; g_b = (p-b)/max(p(1-p),1e-12)  [grad_b_wrt_logit: times p(1-p)] ;
+ *   g_c = gamma*w[y]*(softmax - onehot) ; g_mu = beta*mu ; g_lv = -0.5*beta*(1-exp(lv)).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, A, D, S, L;
+    const float* recon_a; const float* a; int64_t ld_ra, ld_a;
+    const float* recon_b; const float* b; int64_t ld_rb, ld_b;
+    const float* logits; int64_t ld_logits; const int64_t* site; const float* class_weights;
+    const float* mu; const float* logvar;
+    float beta, gamma;
+    double* sums;
+    void* g_a; int32_t g_a_dtype; int64_t ld_ga;
+    void* g_b; int32_t g_b_dtype; int64_t ld_gb; int32_t grad_b_wrt_logit;
+    float* g_c; int64_t ld_gc;
+    float* g_mu; float* g_lv;
+} mmvae_loss_args;
+int mmvae_vae_loss(const mmvae_loss_args* args, void* stream);
+
+/* out = g * p * (1-p): Sigmoid backward for gradients that arrive w.r.t. recon_b (decoders.py:32). */
+int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,
+                      void* out, int32_t out_dtype, int64_t ldo, void* stream);
+
+/* x *= *scale unless *scale == 1 (loss.backward(gradient=...) support); n elements of dtype. */
+int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const float* scale_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Noise: Philox4x32-10 streams keyed by (seed, offset).  Dropout keep mask (nn.Dropout(0.1),
+ * encoders.py:16,34,38; replaces aten::bernoulli_) and standard normal eps
+ * (torch.randn_like, vae.py:14).
+ * ------------------------------------------------------------------------------------------- */
+int mmvae_dropout_mask(uint8_t* mask, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
+int mmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdamW (torch.optim.AdamW, constructed by the caller: optimize_hyperparameters.py:93-97,
+ * train_dna2rna.py:185-189), all tensors in one launch from a device-resident table:
+ *   p *= 1-lr*wd ; m = b1*m+(1-b1)g ; v = b2*v+(1-b2)g^2 ; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } mmvae_adamw_item;
+int mmvae_adamw_step(const mmvae_adamw_item* items_dev, int32_t n_items, int64_t max_numel, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_HIP_H */

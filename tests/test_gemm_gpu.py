@@ -1,0 +1,157 @@
+"""GPU parity of the two MFMA GEMM kernels (through the C ABI) against float64 matmuls.
+
+bf16 mode: operands are rounded to bf16 on the host first, so both sides multiply the SAME
+values and only the f32 accumulation order differs -> tolerance 2e-5 * sqrt(K) * scale.
+f32 mode: v_mfma_f32_16x16x4_f32 is an exact fma chain -> same tolerance.
+Outputs stored as bf16 add one bf16 rounding (2^-9 relative)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmvae import ops  # noqa: E402
+from mmvae.ops import PREC_BF16, PREC_F32  # noqa: E402
+
+DEV = "cuda"
+
+
+def _round(x, prec):
+    return x.to(torch.bfloat16).to(torch.float32) if prec == PREC_BF16 else x
+
+
+def _prep(W, b, prec):
+    pl = ops.PreparedLinear([W], [b], prec, DEV)
+    ops.WeightPrep([pl], DEV).run()
+    return pl
+
+
+def _tol(K, scale, out_bf16=False):
+    return 2e-5 * np.sqrt(K) * scale + (scale * 2.0 ** -8 if out_bf16 else 0.0)
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("M,N,K,a_bf16", [(300, 128, 782, False), (257, 512, 572, False), (128, 40, 77, False),
+                                          (1000, 600, 256, True), (64, 24, 64, True), (31, 130, 20, True)])
+def test_nt_store(prec, M, N, K, a_bf16):
+    if prec == PREC_F32 and a_bf16:
+        pytest.skip("bf16 activations only exist in bf16 mode")
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = _round(torch.randn(M, K, generator=g), prec)
+    W = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    Wd, bd = W.to(DEV), b.to(DEV)
+    pl = _prep(Wd, bd, prec)
+    np.testing.assert_array_equal(pl.w[:N, :K].float().cpu().numpy(), _round(W, prec).numpy())
+    np.testing.assert_array_equal(pl.wt[:K, :N].float().cpu().numpy(), _round(W, prec).t().numpy())
+    assert float(pl.w.float().abs().sum()) == pytest.approx(float(_round(W, prec).abs().sum()), rel=1e-5)
+    if a_bf16:
+        Ad = torch.zeros(M, ops.ceil_to(K, 8), dtype=torch.bfloat16, device=DEV)
+        Ad[:, :K] = A.to(DEV)
+        Ad[:, K:] = float("nan")          # pad garbage must never reach the accumulators
+    else:
+        Ad = A.to(DEV)
+    ref = A.double() @ _round(W, prec).double().t() + b.double()
+    for out_dt in ([torch.float32] if prec == PREC_F32 else [torch.float32, torch.bfloat16]):
+        for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SIGMOID):
+            out = torch.full((M, ops.ceil_to(N, 8)), 7.0, dtype=out_dt, device=DEV)
+            nt = (M + 127) // 128
+            p1 = torch.zeros(nt, ops.ceil_to(N, 128), device=DEV)
+            p2 = torch.zeros_like(p1)
+            ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, act=act, part1=p1, part2=p2)
+            r = ref if act == 0 else (ref.clamp_min(0) if act == 1 else torch.sigmoid(ref))
+            got = out[:, :N].float().cpu().double()
+            tol = _tol(K, float(r.abs().max()), out_dt == torch.bfloat16)
+            assert float((got - r).abs().max()) <= tol, (act, out_dt)
+            assert torch.all(out[:, N:].float() == 7.0)          # nothing written outside [M,N]
+            np.testing.assert_allclose(p1[:, :N].sum(0).cpu().double(), got.sum(0), rtol=1e-4, atol=1e-2)
+            np.testing.assert_allclose(p2[:, :N].sum(0).cpu().double(), (got ** 2).sum(0), rtol=1e-4, atol=1e-2)
+    # accumulate
+    out = torch.ones(M, N, device=DEV)
+    ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, accumulate=True)
+    assert float((out.cpu().double() - (ref + 1.0)).abs().max()) <= _tol(K, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("M,N,K", [(1000, 40, 128), (4096, 512, 572), (333, 128, 782), (2048, 782, 128), (130, 24, 64)])
+def test_tn(prec, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    lp = prec == PREC_BF16
+    P = _round(torch.randn(M, N, generator=g), prec)
+    Q = _round(torch.randn(M, K, generator=g), prec)
+    ref = P.double().t() @ Q.double()
+    refb = P.double().sum(0)
+    variants = [("f32", "f32")] + ([("bf16", "f32"), ("bf16", "bf16"), ("f32", "bf16")] if lp else [])
+    for pk, qk in variants:
+        def mk(X, kind):
+            if kind == "f32":
+                return X.to(DEV)
+            t = torch.full((M, ops.ceil_to(X.shape[1], 8)), float("nan"), dtype=torch.bfloat16, device=DEV)
+            t[:, :X.shape[1]] = X.to(DEV)
+            return t
+        Pd, Qd = mk(P, pk), mk(Q, qk)
+        for nsplit in (0, 1, 3):
+            dw = torch.zeros(N, K, device=DEV)
+            db = torch.zeros(N, device=DEV)
+            ops.gemm_tn(prec, Pd, Qd, dw, db, N, K, nsplit=nsplit)
+            tol = 2e-5 * np.sqrt(M) * float(ref.abs().max())
+            assert float((dw.cpu().double() - ref).abs().max()) <= tol, (pk, qk, nsplit)
+            assert float((db.cpu().double() - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4
+    # accumulation into non-zero dw
+    dw = torch.ones(N, K, device=DEV); db = torch.ones(N, device=DEV)
+    ops.gemm_tn(prec, P.to(DEV), Q.to(DEV), dw, db, N, K)
+    assert float((dw.cpu().double() - ref - 1).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_bn_relu_drop_prologue_and_bwd_epilogues(prec, with_mask):
+    M, K, N = 700, 256, 136
+    g = torch.Generator().manual_seed(5)
+    adt = ops.act_dtype(prec)
+    y = _round(torch.randn(M, K, generator=g), prec)
+    scale = torch.rand(K, generator=g) + 0.5
+    shift = torch.randn(K, generator=g) * 0.3
+    mask = (torch.rand(M, K, generator=g) < 0.9).to(torch.uint8) if with_mask else None
+    inv_keep = 1.0 / 0.9 if with_mask else 1.0
+    W = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    pl = _prep(W.to(DEV), b.to(DEV), prec)
+    h = torch.relu(y * scale + shift) * (mask.float() * inv_keep if with_mask else 1.0)
+    hq = _round(h, prec)
+    ref = hq.double() @ _round(W, prec).double().t() + b.double()
+    yd = y.to(DEV).to(adt)
+    md = mask.to(DEV) if with_mask else None
+    pro = (scale.to(DEV), shift.to(DEV), md, inv_keep)
+    out = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(prec, yd, pl.w, N, K, out, bias=pl.bias, prologue=pro)
+    assert float((out.cpu().double() - ref).abs().max()) <= _tol(K, float(ref.abs().max()))
+    # TN with the same prologue on Q
+    P = _round(torch.randn(M, 40, generator=g), prec)
+    dw = torch.zeros(40, K, device=DEV); db = torch.zeros(40, device=DEV)
+    ops.gemm_tn(prec, P.to(DEV), yd, dw, db, 40, K, q_prologue=pro)
+    refw = P.double().t() @ hq.double()
+    assert float((dw.cpu().double() - refw).abs().max()) <= 2e-5 * np.sqrt(M) * float(refw.abs().max())
+
+    # dX GEMM with EPI_RELU_MASK:  dH = (dY @ W) * (H > 0)
+    dY = _round(torch.randn(M, N, generator=g), prec)
+    H = _round(torch.relu(torch.randn(M, K, generator=g)), prec)
+    refd = (dY.double() @ _round(W, prec).double()) * (H > 0)
+    outd = torch.zeros(M, K, dtype=adt, device=DEV)
+    ops.gemm_nt(prec, dY.to(DEV).to(adt), pl.wt, K, N, outd, epilogue=ops.EPI_RELU_MASK, h=H.to(DEV).to(adt))
+    assert float((outd.float().cpu().double() - refd).abs().max()) <= _tol(N, float(refd.abs().max()), prec == PREC_BF16)
+
+    # dX GEMM with EPI_BN_BWD: d = (dY @ W) * keep * (y*scale+shift > 0); partials (sum d, sum d*xhat)
+    mean = torch.randn(K, generator=g) * 0.1
+    rstd = torch.rand(K, generator=g) + 0.5
+    nt = (M + 127) // 128
+    p1 = torch.zeros(nt, K, device=DEV); p2 = torch.zeros(nt, K, device=DEV)
+    ops.gemm_nt(prec, dY.to(DEV).to(adt), pl.wt, K, N, outd, epilogue=ops.EPI_BN_BWD, h=yd,
+                bn=(scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), md, inv_keep), part1=p1, part2=p2)
+    keep = mask.double() * inv_keep if with_mask else 1.0
+    refd = (dY.double() @ _round(W, prec).double()) * keep * ((y * scale + shift) > 0)
+    got = outd.float().cpu().double()
+    assert float((got - refd).abs().max()) <= _tol(N, float(refd.abs().max()), prec == PREC_BF16)
+    xhat = (y.double() - mean.double()) * rstd.double()
+    np.testing.assert_allclose(p1.sum(0).cpu().double(), got.sum(0), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(p2.sum(0).cpu().double(), (got * xhat).sum(0), rtol=1e-4, atol=2e-2)

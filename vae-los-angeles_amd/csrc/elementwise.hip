@@ -1,0 +1,539 @@
+// Memory-bound kernels of the MultiModalVAE training path (gfx950): weight preparation,
+// BatchNorm finalisation (forward statistics / backward reductions), EncoderC table,
+// mean-fusion + reparameterisation, the fused loss, Philox noise and multi-tensor AdamW.
+// All of these are HBM- or latency-bound; they use 64-lane wave reductions, vector loads where
+// the caller's row alignment allows, and f64 only for the final cross-block accumulations.
+#include "common.h"
+#include "mmvae_hip.h"
+
+namespace mm {
+
+// ------------------------------------------------------------------------------------------
+// weight preparation
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_weights_kernel(const mmvae_prep_item* __restrict__ items) {
+    const mmvae_prep_item it = items[blockIdx.y];
+    const long total = (long)it.dst_rows * it.dst_cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / it.dst_cols), c = (int)(idx % it.dst_cols);
+        const int sr = it.transpose ? c : r, sc = it.transpose ? r : c;
+        float v = (sr < it.src_rows && sc < it.src_cols) ? it.src[(long)sr * it.src_ld + sc] : 0.f;
+        if (it.dst_dtype == MMVAE_BF16) ((bf16*)it.dst)[(long)r * it.dst_ld + c] = (bf16)v;
+        else ((float*)it.dst)[(long)r * it.dst_ld + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm finalisation.  64 columns per block, 4 partial-row groups per column.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, long ldp, int n_tiles, int col, int N,
+                                                double& s1, double& s2, double (*sh)[2][64]) {
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    if (col < N)
+        for (int t = rg; t < n_tiles; t += 4) { a += (double)p1[(long)t * ldp + col]; b += (double)p2[(long)t * ldp + col]; }
+    sh[rg][0][cg] = a; sh[rg][1][cg] = b;
+    __syncthreads();
+    s1 = sh[0][0][cg] + sh[1][0][cg] + sh[2][0][cg] + sh[3][0][cg];
+    s2 = sh[0][1][cg] + sh[1][1][cg] + sh[2][1][cg] + sh[3][1][cg];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mmvae_bn_finalize_args a) {
+    __shared__ double sh[4][2][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1, s2;
+    reduce_partials(a.part_sum, a.part_sumsq, a.ldp, a.n_tiles, col, a.N, s1, s2, sh);
+    if (threadIdx.x < 64 && col < a.N) {
+        const double mean = s1 / a.M;
+        double var = s2 / a.M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = a.gamma[col] * rstd;
+        a.mean[col] = (float)mean; a.rstd[col] = rstd;
+        a.scale[col] = sc; a.shift[col] = a.beta[col] - (float)mean * sc;
+        if (a.running_mean) {
+            a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * (float)mean;
+            const double unbiased = var * ((double)a.M / (double)(a.M - 1));
+            a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * (float)unbiased;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+}
+
+__global__ void bn_eval_coeffs_kernel(int N, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mmvae_bn_bwd_finalize_args a) {
+    __shared__ double sh[4][2][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    double sd, sdx;
+    reduce_partials(a.part_d, a.part_dx, a.ldp, a.n_tiles, col, a.N, sd, sdx, sh);
+    if (threadIdx.x < 64 && col < a.N) {
+        a.dbeta[col] += (float)sd;
+        a.dgamma[col] += (float)sdx;
+        a.coef[col] = a.gamma[col] * a.rstd[col];
+        a.coef[a.N + col] = (float)(sd / a.M);
+        a.coef[2 * a.N + col] = (float)(sdx / a.M);
+    }
+}
+
+// dy = c0 * (d - c1 - xhat * c2), xhat = (y - mean) * rstd ; V elements per thread, N % V == 0
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int N, T* d, long ldd, const T* y, long ldy,
+                                                            const float* mean, const float* rstd, const float* coef) {
+    const int vpr = N / V;
+    const long total = (long)M * vpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
+        float dv[V], yv[V];
+        VLoad<T, V>::ld(d + (long)r * ldd + c, dv);
+        VLoad<T, V>::ld(y + (long)r * ldy + c, yv);
+        T o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (yv[e] - mean[c + e]) * rstd[c + e];
+            o[e] = from_f32<T>(coef[c + e] * (dv[e] - coef[N + c + e] - xh * coef[2 * N + c + e]));
+        }
+        if constexpr (sizeof(T) * V == 16) *(f32x4*)(d + (long)r * ldd + c) = *(f32x4*)o;
+        else for (int e = 0; e < V; ++e) d[(long)r * ldd + c + e] = o[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// EncoderC table
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_table_fwd_kernel(int S, int E, int L, const float* emb, const float* w_mu,
+                                                               const float* b_mu, const float* w_lv, const float* b_lv, float* table) {
+    for (int i = threadIdx.x; i < S * 2 * L; i += blockDim.x) {
+        const int s = i / (2 * L), j = i % (2 * L);
+        const float* w = j < L ? w_mu + (long)j * E : w_lv + (long)(j - L) * E;
+        float acc = j < L ? b_mu[j] : b_lv[j - L];
+        for (int e = 0; e < E; ++e) acc += emb[(long)s * E + e] * w[e];
+        table[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int L, const float* emb, const float* w_mu,
+                                                               const float* w_lv, const float* dT, float* d_emb, float* d_w_mu,
+                                                               float* d_b_mu, float* d_w_lv, float* d_b_lv) {
+    const int L2 = 2 * L;
+    for (int i = threadIdx.x; i < S * E; i += blockDim.x) {           // dEmb = dT x Wcat
+        const int s = i / E, e = i % E;
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc += dT[s * L2 + j] * w_mu[(long)j * E + e] + dT[s * L2 + L + j] * w_lv[(long)j * E + e];
+        d_emb[i] += acc;
+    }
+    for (int i = threadIdx.x; i < L2 * E; i += blockDim.x) {          // dWcat = dT^T x emb
+        const int j = i / E, e = i % E;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * emb[(long)s * E + e];
+        if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
+    }
+    for (int j = threadIdx.x; j < L2; j += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += dT[s * L2 + j];
+        if (j < L) d_b_mu[j] += acc; else d_b_lv[j - L] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fusion + reparameterisation
+// ------------------------------------------------------------------------------------------
+template <typename ZT>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(mmvae_fuse_fwd_args a) {
+    const long total = (long)a.B * a.ldz;
+    const float inv_n = 1.f / (float)a.n_mod;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.ldz), l = (int)(i % a.ldz);
+        ZT* zp = (ZT*)a.z + i;
+        if (l >= a.L) { *zp = from_f32<ZT>(0.f); continue; }
+        float mu = 0.f, lv = 0.f;
+        if (a.heads_a) { mu += a.heads_a[(long)b * a.ld_heads + l]; lv += a.heads_a[(long)b * a.ld_heads + a.L + l]; }
+        if (a.heads_b) { mu += a.heads_b[(long)b * a.ld_heads + l]; lv += a.heads_b[(long)b * a.ld_heads + a.L + l]; }
+        if (a.table) { const long s = a.site[b]; mu += a.table[s * 2 * a.L + l]; lv += a.table[s * 2 * a.L + a.L + l]; }
+        if (a.n_mod > 1) { mu *= inv_n; lv *= inv_n; }
+        a.mu[(long)b * a.L + l] = mu; a.logvar[(long)b * a.L + l] = lv;
+        *zp = from_f32<ZT>(mu + a.eps[(long)b * a.L + l] * expf(0.5f * lv));
+    }
+}
+
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, int rows_per_block, int use_lds) {
+    extern __shared__ float sT[];                 // [S][2L] when use_lds
+    const int L2 = 2 * a.L;
+    if (use_lds) { for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) sT[i] = 0.f; __syncthreads(); }
+    const int b0 = blockIdx.x * rows_per_block, b1 = min(a.B, b0 + rows_per_block);
+    const float inv_n = 1.f / (float)a.n_mod;
+    for (long i = (long)b0 * a.L + threadIdx.x; i < (long)b1 * a.L; i += blockDim.x) {
+        const int b = (int)(i / a.L), l = (int)(i % a.L);
+        const float dz = a.dz[(long)b * a.lddz + l];
+        const float gm = a.g_mu ? a.g_mu[i] : 0.f, gl = a.g_lv ? a.g_lv[i] : 0.f;
+        float dmu = gm + dz;
+        float dlv = gl + dz * a.eps[i] * expf(0.5f * a.logvar[i]) * 0.5f;
+        if (a.n_mod > 1) { dmu *= inv_n; dlv *= inv_n; }
+        a.d_heads[(long)b * a.ld_heads + l] = dmu;
+        a.d_heads[(long)b * a.ld_heads + a.L + l] = dlv;
+        if (a.d_table) {
+            const long s = a.site[b];
+            if (use_lds) { atomicAdd(&sT[s * L2 + l], dmu); atomicAdd(&sT[s * L2 + a.L + l], dlv); }
+            else { unsafeAtomicAdd(&a.d_table[s * L2 + l], dmu); unsafeAtomicAdd(&a.d_table[s * L2 + a.L + l], dlv); }
+        }
+    }
+    if (use_lds && a.d_table) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) if (sT[i] != 0.f) unsafeAtomicAdd(&a.d_table[i], sT[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused loss
+// ------------------------------------------------------------------------------------------
+template <typename GT, int V>
+__device__ __forceinline__ void store_vec(GT* p, const float* v) {
+    GT o[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = from_f32<GT>(v[e]);
+    if constexpr (sizeof(GT) * V == 16) *(f32x4*)p = *(f32x4*)o;
+    else if constexpr (sizeof(GT) * V == 8) *(f32x2*)p = *(f32x2*)o;
+    else if constexpr (sizeof(GT) * V == 4) *(float*)p = *(float*)o;
+    else for (int e = 0; e < V; ++e) p[e] = o[e];
+}
+
+template <typename GT, int V>
+__device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, long stride) {
+    float acc = 0.f;
+    const int vpr = a.A / V;
+    const long total = (long)a.B * vpr;
+    for (long i = tid0; i < total; i += stride) {
+        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
+        float x[V], t[V], g[V];
+        VLoad<float, V>::ld(a.recon_a + (long)r * a.ld_ra + c, x);
+        VLoad<float, V>::ld(a.a + (long)r * a.ld_a + c, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float d = x[e] - t[e]; acc += d * d; g[e] = 2.f * d; }
+        if (a.g_a) store_vec<GT, V>((GT*)a.g_a + (long)r * a.ld_ga + c, g);
+    }
+    return acc;
+}
+
+template <typename GT, int V>
+__device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, long stride) {
+    float acc = 0.f;
+    const int vpr = a.D / V;
+    const long total = (long)a.B * vpr;
+    for (long i = tid0; i < total; i += stride) {
+        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
+        float p[V], t[V], g[V];
+        VLoad<float, V>::ld(a.recon_b + (long)r * a.ld_rb + c, p);
+        VLoad<float, V>::ld(a.b + (long)r * a.ld_b + c, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float lp = fmaxf(logf(p[e]), -100.f), l1p = fmaxf(log1pf(-p[e]), -100.f);
+            acc -= t[e] * lp + (1.f - t[e]) * l1p;
+            const float pq = (1.f - p[e]) * p[e];
+            g[e] = (p[e] - t[e]) / fmaxf(pq, 1e-12f);
+            if (a.grad_b_wrt_logit) g[e] *= pq;
+        }
+        if (a.g_b) store_vec<GT, V>((GT*)a.g_b + (long)r * a.ld_gb + c, g);
+    }
+    return acc;
+}
+
+template <typename GT, int VA, int VD>
+__global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
+    const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.recon_a) s[0] = mse_part<GT, VA>(a, tid0, stride);
+    if (a.recon_b) s[1] = bce_part<GT, VD>(a, tid0, stride);
+    if (a.logits) {
+        for (long r = tid0; r < a.B; r += stride) {
+            const float* lg = a.logits + r * a.ld_logits;
+            const long y = a.site[r];
+            float m = -INFINITY;
+            for (int j = 0; j < a.S; ++j) m = fmaxf(m, lg[j]);
+            float se = 0.f;
+            for (int j = 0; j < a.S; ++j) se += expf(lg[j] - m);
+            const float lse = m + logf(se);
+            const float w = a.class_weights ? a.class_weights[y] : 1.f;
+            s[2] += w * (lse - lg[y]);
+            if (a.g_c) {
+                float* g = a.g_c + r * a.ld_gc;
+                for (int j = 0; j < a.S; ++j) g[j] = a.gamma * w * (expf(lg[j] - lse) - (j == y ? 1.f : 0.f));
+            }
+        }
+    }
+    if (a.mu) {
+        const long total = (long)a.B * a.L;
+        for (long i = tid0; i < total; i += stride) {
+            const float mu = a.mu[i], lv = a.logvar[i], ex = expf(lv);
+            s[3] += -0.5f * (1.f + lv - mu * mu - ex);
+            if (a.g_mu) a.g_mu[i] = a.beta * mu;
+            if (a.g_lv) a.g_lv[i] = -0.5f * a.beta * (1.f - ex);
+        }
+    }
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float v = wave_sum(s[k]); if (lane == 0) red[wid][k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+        if (v != 0.0) unsafeAtomicAdd(a.sums + threadIdx.x, v);
+    }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(int M, int N, const float* g, long ldg, const float* p, long ldp,
+                                                           OT* out, long ldo) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i % N);
+        const float pv = p[(long)r * ldp + c];
+        out[(long)r * ldo + c] = from_f32<OT>(g[(long)r * ldg + c] * pv * (1.f - pv));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_if_needed_kernel(T* x, long n, const float* scale) {
+    const float s = *scale;
+    if (s == 1.f) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = from_f32<T>(to_f32(x[i]) * s);
+}
+
+// ------------------------------------------------------------------------------------------
+// noise
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, long n, uint32_t thresh, uint64_t seed, uint64_t offset) {
+    const long nq = (n + 15) / 16;                 // 16 mask bytes per thread-iteration
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t r[4];
+            Philox::gen(seed, offset + (uint64_t)q * 4 + k, 0x4D41534Bull /* "MASK" */, r);
+            w[k] = (r[0] < thresh ? 1u : 0u) | (r[1] < thresh ? 0x100u : 0u) | (r[2] < thresh ? 0x10000u : 0u) | (r[3] < thresh ? 0x1000000u : 0u);
+        }
+        if (q * 16 + 16 <= n) { uint4 v = {w[0], w[1], w[2], w[3]}; *(uint4*)(mask + q * 16) = v; }
+        else for (long i = q * 16; i < n; ++i) mask[i] = (uint8_t)((w[(i - q * 16) >> 2] >> (8 * ((i - q * 16) & 3))) & 0xff);
+    }
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t seed, uint64_t offset) {
+    const long nq = (n + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        uint32_t r[4];
+        Philox::gen(seed, offset + (uint64_t)q, 0x4E4F524Dull /* "NORM" */, r);
+        float z[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {               // Box-Muller on (0,1] x [0,1)
+            const float u1 = ((float)(r[2 * k] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(r[2 * k + 1] >> 8) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * k] = rad * cs; z[2 * k + 1] = rad * sn;
+        }
+        for (int k = 0; k < 4; ++k) if (q * 4 + k < n) out[q * 4 + k] = z[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW, all tensors in one launch
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(const mmvae_adamw_item* __restrict__ items, float lr, float b1, float b2,
+                                                     float eps, float wd, float bc1, float rsqrt_bc2, int maximize) {
+    const mmvae_adamw_item it = items[blockIdx.y];
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < it.n; i += (long)gridDim.x * blockDim.x) {
+        float g = it.g[i];
+        if (maximize) g = -g;
+        float p = it.p[i] * (1.f - lr * wd);
+        const float m = b1 * it.m[i] + (1.f - b1) * g;
+        const float v = b2 * it.v[i] + (1.f - b2) * g * g;
+        p -= step * m / (sqrtf(v) * rsqrt_bc2 + eps);
+        it.p[i] = p; it.m[i] = m; it.v[i] = v;
+    }
+}
+
+static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
+    long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" int mmvae_abi_version(void) { return 1; }
+
+extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
+    if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(64, n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_finalize(const mmvae_bn_finalize_args* a, void* stream) {
+    if (!a || !a->part_sum || !a->part_sumsq || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->scale || !a->shift) return MMVAE_ERR_ARG;
+    if (a->M < 2 || a->N <= 0 || a->n_tiles <= 0) return MMVAE_ERR_ARG;      /* BatchNorm1d needs > 1 row in training */
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float eps, float* scale, float* shift, void* stream) {
+    if (N <= 0 || !gamma || !beta || !rm || !rv || !scale || !shift) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, gamma, beta, rm, rv, eps, scale, shift);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* a, void* stream) {
+    if (!a || !a->part_d || !a->part_dx || !a->gamma || !a->rstd || !a->dgamma || !a->dbeta || !a->coef) return MMVAE_ERR_ARG;
+    if (a->M <= 0 || a->N <= 0 || a->n_tiles <= 0) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                                  const float* mean, const float* rstd, const float* coef, void* stream) {
+    if (M <= 0 || N <= 0 || !d || !y || !mean || !rstd || !coef) return MMVAE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMVAE_BF16) {
+        if (N % 8 || ldd % 8 || ldy % 8 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 8>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef);
+    } else {
+        if (N % 4 || ldd % 4 || ldy % 4 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(grid_for((long)M * N / 4)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef);
+    }
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_embed_table_fwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* b_mu,
+                                     const float* w_lv, const float* b_lv, float* table, void* stream) {
+    if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !b_mu || !w_lv || !b_lv || !table) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(embed_table_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, E, L, emb, w_mu, b_mu, w_lv, b_lv, table);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* w_lv,
+                                     const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
+                                     float* d_b_lv, void* stream) {
+    if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !w_lv || !d_table || !d_emb || !d_w_mu || !d_b_mu || !d_w_lv || !d_b_lv) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(embed_table_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_fuse_reparam_fwd(const mmvae_fuse_fwd_args* a, void* stream) {
+    if (!a || a->B <= 0 || a->L <= 0 || !a->eps || !a->mu || !a->logvar || !a->z || a->ldz < a->L) return MMVAE_ERR_ARG;
+    const int present = (a->heads_a != nullptr) + (a->heads_b != nullptr) + (a->table != nullptr);
+    if (present == 0 || present != a->n_mod) return MMVAE_ERR_ARG;
+    if (a->table && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
+    const int grid = grid_for((long)a->B * a->ldz);
+    if (a->z_dtype == MMVAE_BF16) hipLaunchKernelGGL(fuse_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(fuse_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* a, void* stream) {
+    if (!a || a->B <= 0 || a->L <= 0 || a->n_mod <= 0 || !a->dz || !a->eps || !a->logvar || !a->d_heads) return MMVAE_ERR_ARG;
+    if (a->d_table && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
+    const int rows_per_block = 256;
+    const int grid = (a->B + rows_per_block - 1) / rows_per_block;
+    const size_t lds = a->d_table ? (size_t)a->S * 2 * a->L * sizeof(float) : 0;
+    const int use_lds = lds > 0 && lds <= 48 * 1024;
+    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(grid), dim3(256), use_lds ? lds : 0, (hipStream_t)stream, *a, rows_per_block, use_lds);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename GT>
+static int launch_loss(const mmvae_loss_args* a, hipStream_t st) {
+    auto al = [](const void* p, int64_t ld, int v, size_t es) { return p == nullptr || (ld % v == 0 && ((uintptr_t)p % (v * es)) == 0); };
+    int va = 1, vd = 1;
+    for (int v : {4, 2}) {
+        if (va == 1 && a->recon_a && a->A % v == 0 && al(a->recon_a, a->ld_ra, v, 4) && al(a->a, a->ld_a, v, 4) && al(a->g_a, a->ld_ga, v, sizeof(GT))) va = v;
+        if (vd == 1 && a->recon_b && a->D % v == 0 && al(a->recon_b, a->ld_rb, v, 4) && al(a->b, a->ld_b, v, 4) && al(a->g_b, a->ld_gb, v, sizeof(GT))) vd = v;
+    }
+    const long work = (long)a->B * ((a->recon_a ? a->A / va : 0) + (a->recon_b ? a->D / vd : 0) + 1);
+    const int grid = mm::grid_for(work, 256 * 4, 2048);
+#define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a)
+    if (va == 4 && vd == 4) MM_LOSS(4, 4); else if (va == 4 && vd == 2) MM_LOSS(4, 2); else if (va == 4) MM_LOSS(4, 1);
+    else if (va == 2 && vd == 4) MM_LOSS(2, 4); else if (va == 2 && vd == 2) MM_LOSS(2, 2); else if (va == 2) MM_LOSS(2, 1);
+    else if (vd == 4) MM_LOSS(1, 4); else if (vd == 2) MM_LOSS(1, 2); else MM_LOSS(1, 1);
+#undef MM_LOSS
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_vae_loss(const mmvae_loss_args* a, void* stream) {
+    if (!a || a->B <= 0 || !a->sums) return MMVAE_ERR_ARG;
+    if (a->recon_a && (!a->a || a->A <= 0)) return MMVAE_ERR_ARG;
+    if (a->recon_b && (!a->b || a->D <= 0)) return MMVAE_ERR_ARG;
+    if (a->logits && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
+    if (a->mu && (!a->logvar || a->L <= 0)) return MMVAE_ERR_ARG;
+    const int gdt = a->g_a ? a->g_a_dtype : a->g_b_dtype;
+    if (a->g_a && a->g_b && a->g_a_dtype != a->g_b_dtype) return MMVAE_ERR_DTYPE;
+    if (gdt == MMVAE_BF16) return launch_loss<bf16>(a, (hipStream_t)stream);
+    return launch_loss<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,
+                                 void* out, int32_t out_dtype, int64_t ldo, void* stream) {
+    if (M <= 0 || N <= 0 || !g || !p || !out) return MMVAE_ERR_ARG;
+    const int grid = grid_for((long)M * N);
+    if (out_dtype == MMVAE_BF16) hipLaunchKernelGGL(sigmoid_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, g, ldg, p, ldpp, (bf16*)out, ldo);
+    else hipLaunchKernelGGL(sigmoid_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, g, ldg, p, ldpp, (float*)out, ldo);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const float* scale_dev, void* stream) {
+    if (!x || n <= 0 || !scale_dev) return MMVAE_ERR_ARG;
+    const int grid = grid_for(n);
+    if (dtype == MMVAE_BF16) hipLaunchKernelGGL(scale_if_needed_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16*)x, n, scale_dev);
+    else hipLaunchKernelGGL(scale_if_needed_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, n, scale_dev);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_dropout_mask(uint8_t* mask, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream) {
+    if (!mask || n <= 0 || keep_prob < 0.f || keep_prob > 1.f || ((uintptr_t)mask & 15)) return MMVAE_ERR_ARG;
+    const double t = (double)keep_prob * 4294967296.0;
+    const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, mask, n, thresh, seed, offset);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n <= 0) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_dev, int32_t n_items, int64_t max_numel, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
+                                void* stream) {
+    if (!items_dev || n_items <= 0 || max_numel <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return MMVAE_ERR_ARG;
+    const int gx = grid_for(max_numel, 256 * 4, 256);
+    hipLaunchKernelGGL(adamw_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, items_dev, lr, beta1, beta2, eps,
+                       weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize);
+    MM_CHECK_LAUNCH();
+    return 0;
+}

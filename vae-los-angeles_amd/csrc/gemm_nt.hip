@@ -1,0 +1,292 @@
+// NT GEMM for gfx950:  C[M,N] = epilogue( prologue(A)[M,K] * W[N,K]^T )
+//
+// Replaces, on the MultiModalVAE training path (reference file:line):
+//   * every nn.Linear forward  (src/models/encoders.py:13,18-19,31,35,40-41,54-55;
+//     src/models/decoders.py:13,15,27,29,31,44,46)  -> aten::addmm
+//   * the dX half of every Linear backward (autograd mm, optimize_hyperparameters.py:112),
+//     with W^T prepared as the "weight" operand
+//   * fused around the contraction: BatchNorm1d-normalise + ReLU + Dropout of the PREVIOUS
+//     layer as the A-operand prologue (encoders.py:14-16,32-34,36-38), bias / ReLU / Sigmoid
+//     epilogues (decoders.py:14,28,30,32), BatchNorm batch statistics (sum, sum of squares per
+//     column) and the ReLU / BN-ReLU-Dropout backward masks as epilogues.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 each = 4x4 MFMA
+// 16x16 tiles), one K step = 128 bytes per LDS row (64 bf16 / 32 f32), XOR-swizzled 16-byte
+// chunks so that ds_read_b128 fragment reads are bank-conflict free.  A and W tiles are
+// register-staged (global -> VGPR -> [convert / prologue] -> LDS) with the next K step's
+// global loads in flight under the current step's MFMAs.  blockIdx -> tile mapping keeps all
+// column tiles of one row tile on one XCD (shared L2) in adjacent dispatch slots.
+#include "common.h"
+#include "mmvae_hip.h"
+#include "gemm_src.h"
+
+namespace mm {
+
+// ------------------------------------------------------------------------------------------
+// Epilogues.  apply() is called once per owned (row, col) with the f32 accumulator; s1/s2 are
+// per-column partial sums reduced over the tile's rows afterwards when STATS is set.
+// ------------------------------------------------------------------------------------------
+template <typename OT, bool STATS_>
+struct EpiStore {               // bias + activation (+ accumulate) ; stats = (sum v, sum v^2)
+    static constexpr bool STATS = STATS_;
+    OT* C; long ldc; const float* bias; int act; int accumulate;
+    float* part1; float* part2; long ldp;
+    struct Col { float b; };
+    __device__ __forceinline__ Col col(int c) const { return Col{bias ? bias[c] : 0.f}; }
+    __device__ __forceinline__ void apply(int row, int c, float v, const Col& cc, float& s1, float& s2) const {
+        v += cc.b;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 1.f / (1.f + expf(-v));
+        OT* q = C + (long)row * ldc + c;
+        if (accumulate) v += to_f32(*q);
+        OT o = from_f32<OT>(v);
+        *q = o;
+        if (STATS) { float r = to_f32(o); s1 += r; s2 += r * r; }
+    }
+};
+
+template <typename OT, typename HT>
+struct EpiReluMask {            // dH = (H > 0) ? v : 0 ; stats = (sum dH, -)
+    static constexpr bool STATS = true;
+    OT* C; long ldc; const HT* H; long ldh;
+    float* part1; float* part2; long ldp;
+    struct Col {};
+    __device__ __forceinline__ Col col(int) const { return Col{}; }
+    __device__ __forceinline__ void apply(int row, int c, float v, const Col&, float& s1, float&) const {
+        float h = to_f32(H[(long)row * ldh + c]);
+        v = h > 0.f ? v : 0.f;
+        OT o = from_f32<OT>(v);
+        C[(long)row * ldc + c] = o;
+        s1 += to_f32(o);
+    }
+};
+
+template <typename OT, typename YT>
+struct EpiBnBwd {               // d_yhat = v * keep * (y*scale+shift > 0) ; stats = (sum d, sum d*xhat)
+    static constexpr bool STATS = true;
+    OT* C; long ldc; const YT* Y; long ldy;
+    const float* scale; const float* shift; const float* mean; const float* rstd;
+    const uint8_t* mask; long ldm; float inv_keep;
+    float* part1; float* part2; long ldp;
+    struct Col { float sc, sh, mu, rs; };
+    __device__ __forceinline__ Col col(int c) const { return Col{scale[c], shift[c], mean[c], rstd[c]}; }
+    __device__ __forceinline__ void apply(int row, int c, float v, const Col& cc, float& s1, float& s2) const {
+        float y = to_f32(Y[(long)row * ldy + c]);
+        float keep = mask ? (mask[(long)row * ldm + c] ? inv_keep : 0.f) : 1.f;
+        float d = (y * cc.sc + cc.sh > 0.f) ? v * keep : 0.f;
+        OT o = from_f32<OT>(d);
+        C[(long)row * ldc + c] = o;
+        float dr = to_f32(o);
+        s1 += dr; s2 += dr * (y - cc.mu) * cc.rs;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+template <typename CT, typename Src, typename Epi>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
+{
+    constexpr int EPC = Mma<CT>::EPC;
+    constexpr int BK = ROW_BYTES / (int)sizeof(CT);
+    typedef typename Mma<CT>::frag frag;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * ROW_BYTES + 4096 + 2048];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + TILE * ROW_BYTES;
+    float* aux = (float*)(smem + 2 * TILE * ROW_BYTES);
+    float* red = (float*)(smem + 2 * TILE * ROW_BYTES + 4096);
+
+    // XCD-aware tile assignment: linear id L runs on XCD L%8 (round-robin dispatch, speed only).
+    const int L = blockIdx.x;
+    const int slot = L >> 3;
+    const int ct = slot % gy;
+    const int rt = (slot / gy) * 8 + (L & 7);
+    if (rt >= gx) return;
+    const int row0 = rt * TILE, col0 = ct * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    if (Src::NEEDS_AUX) { src.init(aux, tid); __syncthreads(); }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typename Src::Raw ra[4];
+    Chunk<CT> rb[4];
+    const int nk = (K + BK - 1) / BK;
+
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
+            src.fetch(ra[i], row0 + r, kt * BK + ch * EPC);
+            rb[i].v = *(const decltype(rb[i].v)*)(W + (long)(col0 + r) * ldw + kt * BK + ch * EPC);
+        }
+    };
+    auto stage = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
+            Chunk<CT> o;
+            src.finish(ra[i], row0 + r, kt * BK + ch * EPC, o, aux);
+            *(decltype(o.v)*)(sA + swz(r, ch)) = o.v;
+            *(decltype(o.v)*)(sB + swz(r, ch)) = rb[i].v;
+        }
+    };
+
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        stage(kt);
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            frag af[4], bf[4];
+            const int ch = s * 4 + (lane >> 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *(const frag*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = *(const frag*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], af[m], bf[n]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int c = col0 + wc * 64 + n * 16 + (lane & 15);
+        if (c < N) {
+            typename Epi::Col cc = epi.col(c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = row0 + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+                    if (r < M) epi.apply(r, c, acc[m][n][j], cc, s1[n], s2[n]);
+                }
+        }
+    }
+    if (Epi::STATS) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s1[n] += __shfl_xor(s1[n], 16, 64); s1[n] += __shfl_xor(s1[n], 32, 64);
+            s2[n] += __shfl_xor(s2[n], 16, 64); s2[n] += __shfl_xor(s2[n], 32, 64);
+            if (lane < 16) {
+                red[(wr * 2 + 0) * TILE + wc * 64 + n * 16 + lane] = s1[n];
+                red[(wr * 2 + 1) * TILE + wc * 64 + n * 16 + lane] = s2[n];
+            }
+        }
+        __syncthreads();
+        if (tid < TILE && col0 + tid < N) {
+            if (epi.part1) epi.part1[(long)rt * epi.ldp + col0 + tid] = red[0 * TILE + tid] + red[2 * TILE + tid];
+            if (epi.part2) epi.part2[(long)rt * epi.ldp + col0 + tid] = red[1 * TILE + tid] + red[3 * TILE + tid];
+        }
+    }
+}
+
+template <typename CT, typename Src, typename Epi>
+static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    int gx = (M + TILE - 1) / TILE, gy = (N + TILE - 1) / TILE;
+    int grid = ((gx + 7) / 8) * 8 * gy;
+    hipLaunchKernelGGL((gemm_nt_kernel<CT, Src, Epi>), dim3(grid), dim3(NTHREADS), 0, st,
+                       src, (const CT*)W, ldw, M, N, K, gx, gy, epi);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename CT, typename Src>
+static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t st) {
+    const bool out_lp = a->c_dtype == MMVAE_BF16;
+    if (a->prec == MMVAE_PREC_F32 && out_lp) return MMVAE_ERR_DTYPE;
+    typedef CT LP;   // low-precision activation type of this precision mode
+    switch (a->epilogue) {
+    case MMVAE_EPI_STORE: {
+        const bool stats = a->part1 != nullptr || a->part2 != nullptr;
+        if (a->c_dtype == MMVAE_F32) {
+            if (stats) { EpiStore<float, true> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, a->part1, a->part2, a->ldp};
+                         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st); }
+            EpiStore<float, false> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, nullptr, 0};
+            return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
+        } else {
+            if constexpr (sizeof(CT) == 2) {
+                if (stats) { EpiStore<bf16, true> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, a->part1, a->part2, a->ldp};
+                             return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st); }
+                EpiStore<bf16, false> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, nullptr, 0};
+                return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
+            }
+            return MMVAE_ERR_DTYPE;
+        }
+    }
+    case MMVAE_EPI_RELU_MASK: {     // C and H are activation-typed (bf16 in bf16 mode, f32 in f32 mode)
+        if (a->h == nullptr) return MMVAE_ERR_ARG;
+        if ((a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
+        EpiReluMask<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->part1, a->part2, a->ldp};
+        return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
+    }
+    case MMVAE_EPI_BN_BWD: {
+        if (a->h == nullptr || !a->bn_scale || !a->bn_shift || !a->bn_mean || !a->bn_rstd) return MMVAE_ERR_ARG;
+        if ((a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
+        EpiBnBwd<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd,
+                           a->epi_mask, a->ld_epi_mask, a->epi_inv_keep, a->part1, a->part2, a->ldp};
+        return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
+    }
+    }
+    return MMVAE_ERR_ARG;
+}
+
+template <typename CT>
+static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
+    constexpr int EPC = Mma<CT>::EPC;
+    if (a->prologue == MMVAE_PRO_BN_RELU_DROP) {
+        // A must be the activation type of this precision mode, 16-byte aligned rows
+        if ((a->a_dtype == MMVAE_BF16) != (sizeof(CT) == 2)) return MMVAE_ERR_DTYPE;
+        if (a->K > 512 || a->lda % EPC || ((uintptr_t)a->a & 15) || !a->pro_scale || !a->pro_shift) return MMVAE_ERR_ARG;
+        if (a->pro_mask && (a->ld_pro_mask % 4 || ((uintptr_t)a->pro_mask & 3))) return MMVAE_ERR_ARG;
+        SrcBnReluDrop<CT> s{(const CT*)a->a, a->lda, a->M, a->K, a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep};
+        return dispatch_epi<CT>(a, s, st);
+    }
+    if (a->a_dtype == MMVAE_BF16) {
+        if constexpr (sizeof(CT) == 2) {
+            if (a->lda % 8 || ((uintptr_t)a->a & 15)) return MMVAE_ERR_ARG;
+            SrcPlain<CT, bf16, 8> s{(const bf16*)a->a, a->lda, a->M, a->K};
+            return dispatch_epi<CT>(a, s, st);
+        }
+        return MMVAE_ERR_DTYPE;
+    }
+    // f32 source with whatever alignment the caller's tensor has (e.g. (B,782): 8-byte rows)
+    const uintptr_t p = (uintptr_t)a->a;
+    if (a->lda % 4 == 0 && a->K % 4 == 0 && (p & 15) == 0) {
+        SrcPlain<CT, float, 4> s{(const float*)a->a, a->lda, a->M, a->K};
+        return dispatch_epi<CT>(a, s, st);
+    }
+    if (a->lda % 2 == 0 && a->K % 2 == 0 && (p & 7) == 0) {
+        SrcPlain<CT, float, 2> s{(const float*)a->a, a->lda, a->M, a->K};
+        return dispatch_epi<CT>(a, s, st);
+    }
+    SrcPlain<CT, float, 1> s{(const float*)a->a, a->lda, a->M, a->K};
+    return dispatch_epi<CT>(a, s, st);
+}
+
+}  // namespace mm
+
+extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
+    if (!a || !a->a || !a->w || !a->c) return MMVAE_ERR_ARG;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
+    if (a->ldw % 64 || ((uintptr_t)a->w & 15)) return MMVAE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->prec == MMVAE_PREC_BF16) return mm::dispatch_src<mm::bf16>(a, st);
+    if (a->prec == MMVAE_PREC_F32) return mm::dispatch_src<float>(a, st);
+    return MMVAE_ERR_ARG;
+}

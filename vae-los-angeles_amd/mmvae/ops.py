@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/mmvae_hip.h).  PyTorch is used here only as
+the owner of device memory and streams; all arithmetic happens in libmmvae_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (F32, BF16, PREC_F32, PREC_BF16, PRO_NONE, PRO_BN_RELU_DROP, EPI_STORE, EPI_RELU_MASK,
+                   EPI_BN_BWD, ACT_NONE, ACT_RELU, ACT_SIGMOID, TILE)
+
+DROP_P = 0.1                      # nn.Dropout(0.1), reference src/models/encoders.py:16,34,38
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # nn.BatchNorm1d defaults, encoders.py:14,32,36
+
+
+def ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def act_dtype(prec):
+    return torch.bfloat16 if prec == PREC_BF16 else torch.float32
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _mat(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU")
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# --------------------------------------------------------------------------------------------
+# prepared weights
+# --------------------------------------------------------------------------------------------
+class PreparedLinear:
+    """MFMA operand copies of one (possibly row-concatenated) Linear: W [ceil128(N)][ceil64(K)]
+    and W^T [ceil128(K)][ceil64(N)] in the compute type, plus the fp32 bias (concatenated if
+    the sources are)."""
+
+    def __init__(self, weights, biases, prec, device):
+        self.N = sum(w.shape[0] for w in weights)
+        self.K = weights[0].shape[1]
+        self.prec = prec
+        dt = act_dtype(prec)
+        self.w = torch.zeros(ceil_to(self.N, TILE), ceil_to(self.K, 64), dtype=dt, device=device)
+        self.wt = torch.zeros(ceil_to(self.K, TILE), ceil_to(self.N, 64), dtype=dt, device=device)
+        self.srcs = list(weights)
+        self.bias_srcs = list(biases)
+        if len(biases) == 1:
+            self.bias = biases[0]
+            self._bias_cat = None
+        else:
+            self._bias_cat = torch.zeros(self.N, dtype=torch.float32, device=device)
+            self.bias = self._bias_cat
+
+    def items(self):
+        out = []
+        dtc = _dt(self.w)
+        row = 0
+        esz = self.w.element_size()
+        for i, w in enumerate(self.srcs):
+            n = w.shape[0]
+            last = i == len(self.srcs) - 1
+            # plain copy: rows [row, row+n) (the last item also clears the padding rows)
+            rows = (self.w.shape[0] - row) if last else n
+            out.append(L.PrepItem(w.data_ptr(), self.w.data_ptr() + row * self.w.stride(0) * esz, n, self.K, w.stride(0),
+                                  rows, self.w.shape[1], self.w.stride(0), 0, dtc))
+            # transposed copy: columns [row, row+n)
+            cols = (self.wt.shape[1] - row) if last else n
+            out.append(L.PrepItem(w.data_ptr(), self.wt.data_ptr() + row * esz, n, self.K, w.stride(0),
+                                  self.wt.shape[0], cols, self.wt.stride(0), 1, dtc))
+            if self._bias_cat is not None:
+                b = self.bias_srcs[i]
+                out.append(L.PrepItem(b.data_ptr(), self._bias_cat.data_ptr() + row * 4, 1, n, n, 1, n, n, 0, F32))
+            row += n
+        return out
+
+
+class WeightPrep:
+    """All PreparedLinears of a module tree, refreshed from the fp32 masters in ONE launch."""
+
+    def __init__(self, linears, device):
+        self.linears = list(linears)
+        items = [it for pl in self.linears for it in pl.items()]
+        self.n = len(items)
+        arr = (L.PrepItem * self.n)(*items)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.to(device)
+        self._keys = self._current_keys()
+
+    def _current_keys(self):
+        return tuple(w.data_ptr() for pl in self.linears for w in pl.srcs + pl.bias_srcs)
+
+    def stale(self):
+        return self._keys != self._current_keys()
+
+    def run(self):
+        L.check(L.load().mmvae_prep_weights(self.table.data_ptr(), self.n, _stream()), "mmvae_prep_weights")
+
+
+# --------------------------------------------------------------------------------------------
+# GEMMs
+# --------------------------------------------------------------------------------------------
+def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
+            epilogue=EPI_STORE, h=None, bn=None, part1=None, part2=None):
+    """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
+    bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD."""
+    _mat(a, "a"); _mat(out, "out"); _mat(w_lp, "w")
+    M = a.shape[0]
+    g = L.GemmNtArgs()
+    g.prec, g.M, g.N, g.K = prec, M, N, K
+    g.a, g.a_dtype, g.lda = a.data_ptr(), _dt(a), _ld(a)
+    if prologue is not None:
+        sc, sh, mask, inv_keep = prologue
+        g.prologue = PRO_BN_RELU_DROP
+        g.pro_scale, g.pro_shift, g.pro_mask = sc.data_ptr(), sh.data_ptr(), _p(mask)
+        g.ld_pro_mask = _ld(mask) if mask is not None else 0
+        g.pro_inv_keep = inv_keep
+    g.w, g.ldw = w_lp.data_ptr(), w_lp.stride(0)
+    g.epilogue = epilogue
+    g.c, g.c_dtype, g.ldc = out.data_ptr(), _dt(out), _ld(out)
+    g.bias, g.act, g.accumulate = _p(bias), act, int(accumulate)
+    if h is not None:
+        g.h, g.ldh = h.data_ptr(), _ld(h)
+    if bn is not None:
+        sc, sh, mean, rstd, mask, inv_keep = bn
+        g.bn_scale, g.bn_shift, g.bn_mean, g.bn_rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        g.epi_mask, g.ld_epi_mask, g.epi_inv_keep = _p(mask), (_ld(mask) if mask is not None else 0), inv_keep
+    if part1 is not None:
+        g.part1, g.ldp = part1.data_ptr(), part1.stride(0)
+    if part2 is not None:
+        g.part2, g.ldp = part2.data_ptr(), part2.stride(0)
+    L.check(L.load().mmvae_gemm_nt(C.byref(g), _stream()), "mmvae_gemm_nt")
+    return out
+
+
+def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0):
+    """dw[N,K] += p[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(p).  dw/db fp32, pre-zeroed."""
+    _mat(p, "p"); _mat(q, "q")
+    g = L.GemmTnArgs()
+    g.prec, g.M, g.N, g.K = prec, p.shape[0], N, K
+    g.p, g.p_dtype, g.ldp = p.data_ptr(), _dt(p), _ld(p)
+    g.q, g.q_dtype, g.ldq = q.data_ptr(), _dt(q), _ld(q)
+    if q_prologue is not None:
+        sc, sh, mask, inv_keep = q_prologue
+        g.q_prologue = PRO_BN_RELU_DROP
+        g.pro_scale, g.pro_shift, g.pro_mask = sc.data_ptr(), sh.data_ptr(), _p(mask)
+        g.ld_pro_mask = _ld(mask) if mask is not None else 0
+        g.pro_inv_keep = inv_keep
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    g.dw, g.lddw, g.db = dw.data_ptr(), K, _p(db)
+    g.nsplit = nsplit
+    L.check(L.load().mmvae_gemm_tn(C.byref(g), _stream()), "mmvae_gemm_tn")
+
+
+# --------------------------------------------------------------------------------------------
+# BatchNorm pieces
+# --------------------------------------------------------------------------------------------
+def bn_finalize(M, N, part_sum, part_sumsq, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
+                eps=BN_EPS, momentum=BN_MOMENTUM):
+    if M < 2:
+        # same failure mode as torch.nn.BatchNorm1d in training mode
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{M}, {N}]")
+    a = L.BnFinalizeArgs(M, N, part_sum.shape[0], part_sum.data_ptr(), part_sumsq.data_ptr(), part_sum.stride(0),
+                         gamma.data_ptr(), beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
+                         mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    L.check(L.load().mmvae_bn_finalize(C.byref(a), _stream()), "mmvae_bn_finalize")
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift, eps=BN_EPS):
+    L.check(L.load().mmvae_bn_eval_coeffs(gamma.numel(), gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                          running_var.data_ptr(), eps, scale.data_ptr(), shift.data_ptr(), _stream()),
+            "mmvae_bn_eval_coeffs")
+
+
+def bn_bwd_finalize(M, N, part_d, part_dx, gamma, rstd, dgamma, dbeta, coef):
+    a = L.BnBwdFinalizeArgs(M, N, part_d.shape[0], part_d.data_ptr(), part_dx.data_ptr(), part_d.stride(0),
+                            gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr())
+    L.check(L.load().mmvae_bn_bwd_finalize(C.byref(a), _stream()), "mmvae_bn_bwd_finalize")
+
+
+def bn_bwd_apply(d, y, N, mean, rstd, coef):
+    L.check(L.load().mmvae_bn_bwd_apply(_dt(d), d.shape[0], N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y),
+                                        mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), _stream()), "mmvae_bn_bwd_apply")
+
+
+# --------------------------------------------------------------------------------------------
+# EncoderC table, fusion, loss, noise, optimiser
+# --------------------------------------------------------------------------------------------
+def embed_table_fwd(emb, w_mu, b_mu, w_lv, b_lv, table):
+    S, E = emb.shape
+    L.check(L.load().mmvae_embed_table_fwd(S, E, w_mu.shape[0], emb.data_ptr(), w_mu.data_ptr(), b_mu.data_ptr(),
+                                           w_lv.data_ptr(), b_lv.data_ptr(), table.data_ptr(), _stream()), "mmvae_embed_table_fwd")
+
+
+def embed_table_bwd(emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv):
+    S, E = emb.shape
+    L.check(L.load().mmvae_embed_table_bwd(S, E, w_mu.shape[0], emb.data_ptr(), w_mu.data_ptr(), w_lv.data_ptr(),
+                                           d_table.data_ptr(), d_emb.data_ptr(), d_w_mu.data_ptr(), d_b_mu.data_ptr(),
+                                           d_w_lv.data_ptr(), d_b_lv.data_ptr(), _stream()), "mmvae_embed_table_bwd")
+
+
+def fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z):
+    n_mod = (heads_a is not None) + (heads_b is not None) + (table is not None)
+    hd = heads_a if heads_a is not None else heads_b
+    a = L.FuseFwdArgs(B, Ld, n_mod, _p(heads_a), _p(heads_b), _ld(hd) if hd is not None else 0,
+                      _p(table), _p(site), table.shape[0] if table is not None else 0,
+                      eps.data_ptr(), mu.data_ptr(), logvar.data_ptr(), z.data_ptr(), _dt(z), _ld(z))
+    L.check(L.load().mmvae_fuse_reparam_fwd(C.byref(a), _stream()), "mmvae_fuse_reparam_fwd")
+
+
+def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dz, eps, logvar, d_heads, d_table, site):
+    a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dz.data_ptr(), _ld(dz), eps.data_ptr(), logvar.data_ptr(),
+                      d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[0] if d_table is not None else 0)
+    L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
+
+
+def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site=None, class_weights=None,
+             mu=None, logvar=None, beta=1e-3, gamma=1.0, sums=None, g_a=None, g_b=None, grad_b_wrt_logit=False,
+             g_c=None, g_mu=None, g_lv=None):
+    x = L.LossArgs()
+    x.B = B
+    if recon_a is not None:
+        x.A, x.recon_a, x.a, x.ld_ra, x.ld_a = recon_a.shape[1], recon_a.data_ptr(), a.data_ptr(), _ld(recon_a), _ld(a)
+    if recon_b is not None:
+        x.D, x.recon_b, x.b, x.ld_rb, x.ld_b = recon_b.shape[1], recon_b.data_ptr(), b.data_ptr(), _ld(recon_b), _ld(b)
+    if logits is not None:
+        x.S, x.logits, x.ld_logits, x.site, x.class_weights = logits.shape[1], logits.data_ptr(), _ld(logits), site.data_ptr(), _p(class_weights)
+    if mu is not None:
+        x.L, x.mu, x.logvar = mu.shape[1], mu.data_ptr(), logvar.data_ptr()
+    x.beta, x.gamma, x.sums = beta, gamma, sums.data_ptr()
+    if g_a is not None:
+        x.g_a, x.g_a_dtype, x.ld_ga = g_a.data_ptr(), _dt(g_a), _ld(g_a)
+    if g_b is not None:
+        x.g_b, x.g_b_dtype, x.ld_gb, x.grad_b_wrt_logit = g_b.data_ptr(), _dt(g_b), _ld(g_b), int(grad_b_wrt_logit)
+    if g_c is not None:
+        x.g_c, x.ld_gc = g_c.data_ptr(), _ld(g_c)
+    x.g_mu, x.g_lv = _p(g_mu), _p(g_lv)
+    L.check(L.load().mmvae_vae_loss(C.byref(x), _stream()), "mmvae_vae_loss")
+
+
+def sigmoid_bwd(g, p, out):
+    L.check(L.load().mmvae_sigmoid_bwd(g.shape[0], g.shape[1], g.data_ptr(), _ld(g), p.data_ptr(), _ld(p), out.data_ptr(),
+                                       _dt(out), _ld(out), _stream()), "mmvae_sigmoid_bwd")
+
+
+def scale_if_needed(x, scale):
+    L.check(L.load().mmvae_scale_if_needed(x.data_ptr(), _dt(x), x.numel(), scale.data_ptr(), _stream()), "mmvae_scale_if_needed")
+
+
+def dropout_mask(mask, keep_prob, seed, offset):
+    L.check(L.load().mmvae_dropout_mask(mask.data_ptr(), mask.numel(), keep_prob, seed, offset, _stream()), "mmvae_dropout_mask")
+
+
+def randn(out, seed, offset):
+    L.check(L.load().mmvae_randn(out.data_ptr(), out.numel(), seed, offset, _stream()), "mmvae_randn")
+
+
+def adamw_step(table, n_items, max_numel, lr, b1, b2, eps, wd, bc1, bc2, maximize=False):
+    L.check(L.load().mmvae_adamw_step(table.data_ptr(), n_items, max_numel, lr, b1, b2, eps, wd, bc1, bc2, int(maximize), _stream()),
+            "mmvae_adamw_step")
