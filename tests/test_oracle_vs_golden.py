@@ -125,6 +125,27 @@ def test_loss_edges():
         np.testing.assert_allclose(g["recon_b"], fx[f"{tag}.grad.recon_b"], rtol=1e-5, atol=1e-6)
 
 
+def test_torch_ref_step_vs_golden():
+    """oracle/torch_ref.py (the timed CPU baseline) reproduces the reference's first step."""
+    import torch
+    import torch_ref as T
+    fx = load("mm_default_b32")
+    A, D, S, L, E = [int(x) for x in fx["dims"]]
+    B, seed = int(fx["B"]), int(fx["seed"])
+    P, Bf = O.make_params(seed, A, D, S, L, E)
+    p, bufs = T.to_torch(P, Bf)
+    masks, eps = O.make_noise(seed + 100, B, L)
+    tm = {k: torch.from_numpy(v.astype(np.float32)) for k, v in masks.items()}
+    a, b, site = torch.from_numpy(fx["a"]), torch.from_numpy(fx["b"]), torch.from_numpy(fx["site"])
+    ra, rb, rc, mu, lv = T.forward(p, bufs, a, b, site, True, tm, torch.from_numpy(eps))
+    loss, rec, cls, kld = T.loss_fn(ra, a, rb, b, rc, site, mu, lv, float(fx["beta"]), float(fx["gamma"]))
+    loss.backward()
+    np.testing.assert_allclose([loss.item(), rec.item(), cls.item(), kld.item()], fx["s0.loss"], rtol=1e-5)
+    expect(fx, "s0.out_b", rb.detach().numpy(), 1e-4, 1e-5)
+    for k, t_ in p.items():
+        expect(fx, "s0.grad." + k, t_.grad.numpy(), 2e-3, 2e-4, scale_atol=3e-4)
+
+
 def test_batchnorm_needs_two_rows():
     P, Bf = O.make_params(1, 8, 8, 3, 2, 4)
     a, b, site = O.make_batch(2, 1, 8, 8, 3)

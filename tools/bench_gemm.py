@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single GEMM launches (through the C ABI) for kernel tuning:
+time vs K (slope = cost of one K step, intercept = prologue + epilogue) and the hot-path shapes.
+    MMVAE_RING=1 python tools/bench_gemm.py        # LDS-ring kernels for plain bf16 operands
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "vae-los-angeles_amd")]
+import torch
+from mmvae import ops
+from mmvae.ops import PREC_BF16
+
+dev = "cuda"
+M = int(os.environ.get("M", 65536))
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3      # us
+
+
+def nt(N, K, a_dtype=torch.bfloat16, out_dtype=torch.bfloat16, epi="store"):
+    A = torch.randn(M, ops.ceil_to(K, 8), device=dev).to(a_dtype)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.zeros(N, device=dev)
+    pl = ops.PreparedLinear([W], [b], PREC_BF16, dev)
+    ops.WeightPrep([pl], dev).run()
+    out = torch.empty(M, ops.ceil_to(N, 8) if out_dtype == torch.bfloat16 else N, dtype=out_dtype, device=dev)
+    if epi == "store":
+        return timeit(lambda: ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, act=1))
+    H = torch.randn(M, ops.ceil_to(N, 8), device=dev).bfloat16()
+    return timeit(lambda: ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, epilogue=ops.EPI_RELU_MASK, h=H))
+
+
+def tn(N, K, q_dtype=torch.bfloat16, nsplit=0):
+    P = torch.randn(M, ops.ceil_to(N, 8), device=dev).bfloat16()
+    Q = torch.randn(M, ops.ceil_to(K, 8) if q_dtype == torch.bfloat16 else K, device=dev).to(q_dtype)
+    dw = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    return timeit(lambda: ops.gemm_tn(PREC_BF16, P, Q, dw, db, N, K, nsplit=nsplit))
+
+
+print("ring enabled" if os.environ.get("MMVAE_RING") else "ring disabled", "M =", M)
+print("NT bf16->bf16 N=128, K sweep:", [(K, round(nt(128, K), 1)) for K in (64, 128, 256, 512, 1024)])
+print("NT bf16->bf16 N=512, K sweep:", [(K, round(nt(512, K), 1)) for K in (64, 128, 256, 512, 1024)])
+print("NT bf16->f32  N=572 K=512 (DecB.L2.fwd):", round(nt(572, 512, out_dtype=torch.float32), 1))
+print("NT bf16->f32  N=782 K=128 (DecA.L1.fwd):", round(nt(782, 128, out_dtype=torch.float32), 1))
+print("NT bf16 relu-mask N=512 K=572 (DecB.L2.dX):", round(nt(512, 572, epi="relu"), 1))
+print("NT f32->bf16  N=512 K=572 (EncB.L0.fwd):", round(nt(512, 572, a_dtype=torch.float32), 1))
+print("TN N=572 K=512 split sweep:", [(s, round(tn(572, 512, nsplit=s), 1)) for s in (0, 8, 16, 32, 64)])
+print("TN N=512 K=572 f32 Q (EncB.L0.dW):", round(tn(512, 572, q_dtype=torch.float32), 1))
+print("TN N=782 K=128 (DecA.L1.dW):", round(tn(782, 128), 1))

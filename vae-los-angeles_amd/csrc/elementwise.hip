@@ -24,28 +24,13 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const mmvae_prep_item
 }
 
 // ------------------------------------------------------------------------------------------
-// BatchNorm finalisation.  64 columns per block, 4 partial-row groups per column.
+// BatchNorm finalisation from the f64 column sums accumulated by the GEMM epilogues.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_partials(const float* p1, const float* p2, long ldp, int n_tiles, int col, int N,
-                                                double& s1, double& s2, double (*sh)[2][64]) {
-    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    double a = 0.0, b = 0.0;
-    if (col < N)
-        for (int t = rg; t < n_tiles; t += 4) { a += (double)p1[(long)t * ldp + col]; b += (double)p2[(long)t * ldp + col]; }
-    sh[rg][0][cg] = a; sh[rg][1][cg] = b;
-    __syncthreads();
-    s1 = sh[0][0][cg] + sh[1][0][cg] + sh[2][0][cg] + sh[3][0][cg];
-    s2 = sh[0][1][cg] + sh[1][1][cg] + sh[2][1][cg] + sh[3][1][cg];
-}
-
 __global__ __launch_bounds__(256) void bn_finalize_kernel(mmvae_bn_finalize_args a) {
-    __shared__ double sh[4][2][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    double s1, s2;
-    reduce_partials(a.part_sum, a.part_sumsq, a.ldp, a.n_tiles, col, a.N, s1, s2, sh);
-    if (threadIdx.x < 64 && col < a.N) {
-        const double mean = s1 / a.M;
-        double var = s2 / a.M - mean * mean;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < a.N) {
+        const double mean = a.sum[col] / a.M;
+        double var = a.sumsq[col] / a.M - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
         const float sc = a.gamma[col] * rstd;
@@ -70,38 +55,14 @@ __global__ void bn_eval_coeffs_kernel(int N, const float* gamma, const float* be
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mmvae_bn_bwd_finalize_args a) {
-    __shared__ double sh[4][2][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    double sd, sdx;
-    reduce_partials(a.part_d, a.part_dx, a.ldp, a.n_tiles, col, a.N, sd, sdx, sh);
-    if (threadIdx.x < 64 && col < a.N) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < a.N) {
+        const double sd = a.sum_d[col], sdx = a.sum_dx[col];
         a.dbeta[col] += (float)sd;
         a.dgamma[col] += (float)sdx;
         a.coef[col] = a.gamma[col] * a.rstd[col];
         a.coef[a.N + col] = (float)(sd / a.M);
         a.coef[2 * a.N + col] = (float)(sdx / a.M);
-    }
-}
-
-// dy = c0 * (d - c1 - xhat * c2), xhat = (y - mean) * rstd ; V elements per thread, N % V == 0
-template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int N, T* d, long ldd, const T* y, long ldy,
-                                                            const float* mean, const float* rstd, const float* coef) {
-    const int vpr = N / V;
-    const long total = (long)M * vpr;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
-        float dv[V], yv[V];
-        VLoad<T, V>::ld(d + (long)r * ldd + c, dv);
-        VLoad<T, V>::ld(y + (long)r * ldy + c, yv);
-        T o[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float xh = (yv[e] - mean[c + e]) * rstd[c + e];
-            o[e] = from_f32<T>(coef[c + e] * (dv[e] - coef[N + c + e] - xh * coef[2 * N + c + e]));
-        }
-        if constexpr (sizeof(T) * V == 16) *(f32x4*)(d + (long)r * ldd + c) = *(f32x4*)o;
-        else for (int e = 0; e < V; ++e) d[(long)r * ldd + c + e] = o[e];
     }
 }
 
@@ -208,15 +169,20 @@ template <typename GT, int V>
 __device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, long stride) {
     float acc = 0.f;
     const int vpr = a.A / V;
-    const long total = (long)a.B * vpr;
-    for (long i = tid0; i < total; i += stride) {
-        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
+    const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
+    for (unsigned i = (unsigned)tid0; i < total; i += (unsigned)stride) {
+        const unsigned r = i / (unsigned)vpr, c = (i - r * (unsigned)vpr) * V;
         float x[V], t[V], g[V];
         VLoad<float, V>::ld(a.recon_a + (long)r * a.ld_ra + c, x);
         VLoad<float, V>::ld(a.a + (long)r * a.ld_a + c, t);
 #pragma unroll
         for (int e = 0; e < V; ++e) { const float d = x[e] - t[e]; acc += d * d; g[e] = 2.f * d; }
-        if (a.g_a) store_vec<GT, V>((GT*)a.g_a + (long)r * a.ld_ga + c, g);
+        if (a.g_a) {
+            GT* gp = (GT*)a.g_a + (long)r * a.ld_ga;
+            store_vec<GT, V>(gp + c, g);
+            if ((int)c + V >= a.A)                       // last vector of the row: zero the pad columns (GEMM operand contract)
+                for (int e = a.A; e < (int)a.ld_ga && e < ((a.A + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+        }
     }
     return acc;
 }
@@ -225,21 +191,26 @@ template <typename GT, int V>
 __device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, long stride) {
     float acc = 0.f;
     const int vpr = a.D / V;
-    const long total = (long)a.B * vpr;
-    for (long i = tid0; i < total; i += stride) {
-        const int r = (int)(i / vpr), c = (int)(i % vpr) * V;
+    const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
+    for (unsigned i = (unsigned)tid0; i < total; i += (unsigned)stride) {
+        const unsigned r = i / (unsigned)vpr, c = (i - r * (unsigned)vpr) * V;
         float p[V], t[V], g[V];
         VLoad<float, V>::ld(a.recon_b + (long)r * a.ld_rb + c, p);
         VLoad<float, V>::ld(a.b + (long)r * a.ld_b + c, t);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float lp = fmaxf(logf(p[e]), -100.f), l1p = fmaxf(log1pf(-p[e]), -100.f);
+            const float lp = fmaxf(__logf(p[e]), -100.f), l1p = fmaxf(__logf(1.f - p[e]), -100.f);   // v_log_f32: 1 ulp, clamp as torch
             acc -= t[e] * lp + (1.f - t[e]) * l1p;
             const float pq = (1.f - p[e]) * p[e];
             g[e] = (p[e] - t[e]) / fmaxf(pq, 1e-12f);
             if (a.grad_b_wrt_logit) g[e] *= pq;
         }
-        if (a.g_b) store_vec<GT, V>((GT*)a.g_b + (long)r * a.ld_gb + c, g);
+        if (a.g_b) {
+            GT* gp = (GT*)a.g_b + (long)r * a.ld_gb;
+            store_vec<GT, V>(gp + c, g);
+            if ((int)c + V >= a.D)
+                for (int e = a.D; e < (int)a.ld_gb && e < ((a.D + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+        }
     }
     return acc;
 }
@@ -285,6 +256,13 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
         const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
         if (v != 0.0) unsafeAtomicAdd(a.sums + threadIdx.x, v);
     }
+}
+
+// out = {total, recon, class, kld} as the reference returns them (losses.py:44,46)
+__global__ void loss_finalize_kernel(const double* sums, float beta, float gamma, float* out) {
+    const double recon = sums[0] + sums[1];
+    out[0] = (float)(recon + (double)gamma * sums[2] + (double)beta * sums[3]);
+    out[1] = (float)recon; out[2] = (float)sums[2]; out[3] = (float)sums[3];
 }
 
 template <typename OT>
@@ -372,7 +350,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 1; }
+extern "C" int mmvae_abi_version(void) { return 3; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -382,9 +360,9 @@ extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_it
 }
 
 extern "C" int mmvae_bn_finalize(const mmvae_bn_finalize_args* a, void* stream) {
-    if (!a || !a->part_sum || !a->part_sumsq || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->scale || !a->shift) return MMVAE_ERR_ARG;
-    if (a->M < 2 || a->N <= 0 || a->n_tiles <= 0) return MMVAE_ERR_ARG;      /* BatchNorm1d needs > 1 row in training */
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+    if (!a || !a->sum || !a->sumsq || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->scale || !a->shift) return MMVAE_ERR_ARG;
+    if (a->M < 2 || a->N <= 0) return MMVAE_ERR_ARG;                          /* BatchNorm1d needs > 1 row in training */
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -398,24 +376,9 @@ extern "C" int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* 
 }
 
 extern "C" int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* a, void* stream) {
-    if (!a || !a->part_d || !a->part_dx || !a->gamma || !a->rstd || !a->dgamma || !a->dbeta || !a->coef) return MMVAE_ERR_ARG;
-    if (a->M <= 0 || a->N <= 0 || a->n_tiles <= 0) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
-    MM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
-                                  const float* mean, const float* rstd, const float* coef, void* stream) {
-    if (M <= 0 || N <= 0 || !d || !y || !mean || !rstd || !coef) return MMVAE_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMVAE_BF16) {
-        if (N % 8 || ldd % 8 || ldy % 8 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 8>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef);
-    } else {
-        if (N % 4 || ldd % 4 || ldy % 4 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(grid_for((long)M * N / 4)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef);
-    }
+    if (!a || !a->sum_d || !a->sum_dx || !a->gamma || !a->rstd || !a->dgamma || !a->dbeta || !a->coef) return MMVAE_ERR_ARG;
+    if (a->M <= 0 || a->N <= 0) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -486,10 +449,18 @@ extern "C" int mmvae_vae_loss(const mmvae_loss_args* a, void* stream) {
     if (a->recon_b && (!a->b || a->D <= 0)) return MMVAE_ERR_ARG;
     if (a->logits && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
     if (a->mu && (!a->logvar || a->L <= 0)) return MMVAE_ERR_ARG;
+    if ((long)a->B * (a->A > a->D ? a->A : a->D) >= (1L << 32)) return MMVAE_ERR_ARG;
     const int gdt = a->g_a ? a->g_a_dtype : a->g_b_dtype;
     if (a->g_a && a->g_b && a->g_a_dtype != a->g_b_dtype) return MMVAE_ERR_DTYPE;
     if (gdt == MMVAE_BF16) return launch_loss<bf16>(a, (hipStream_t)stream);
     return launch_loss<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out4, void* stream) {
+    if (!sums || !out4) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, beta, gamma, out4);
+    MM_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,

@@ -19,72 +19,17 @@
 #include "common.h"
 #include "mmvae_hip.h"
 #include "gemm_src.h"
+#include "gemm_nt_epi.h"
+#include "gemm_ring.h"
 
 namespace mm {
-
-// ------------------------------------------------------------------------------------------
-// Epilogues.  apply() is called once per owned (row, col) with the f32 accumulator; s1/s2 are
-// per-column partial sums reduced over the tile's rows afterwards when STATS is set.
-// ------------------------------------------------------------------------------------------
-template <typename OT, bool STATS_>
-struct EpiStore {               // bias + activation (+ accumulate) ; stats = (sum v, sum v^2)
-    static constexpr bool STATS = STATS_;
-    OT* C; long ldc; const float* bias; int act; int accumulate;
-    float* part1; float* part2; long ldp;
-    struct Col { float b; };
-    __device__ __forceinline__ Col col(int c) const { return Col{bias ? bias[c] : 0.f}; }
-    __device__ __forceinline__ void apply(int row, int c, float v, const Col& cc, float& s1, float& s2) const {
-        v += cc.b;
-        if (act == 1) v = fmaxf(v, 0.f);
-        else if (act == 2) v = 1.f / (1.f + expf(-v));
-        OT* q = C + (long)row * ldc + c;
-        if (accumulate) v += to_f32(*q);
-        OT o = from_f32<OT>(v);
-        *q = o;
-        if (STATS) { float r = to_f32(o); s1 += r; s2 += r * r; }
-    }
-};
-
-template <typename OT, typename HT>
-struct EpiReluMask {            // dH = (H > 0) ? v : 0 ; stats = (sum dH, -)
-    static constexpr bool STATS = true;
-    OT* C; long ldc; const HT* H; long ldh;
-    float* part1; float* part2; long ldp;
-    struct Col {};
-    __device__ __forceinline__ Col col(int) const { return Col{}; }
-    __device__ __forceinline__ void apply(int row, int c, float v, const Col&, float& s1, float&) const {
-        float h = to_f32(H[(long)row * ldh + c]);
-        v = h > 0.f ? v : 0.f;
-        OT o = from_f32<OT>(v);
-        C[(long)row * ldc + c] = o;
-        s1 += to_f32(o);
-    }
-};
-
-template <typename OT, typename YT>
-struct EpiBnBwd {               // d_yhat = v * keep * (y*scale+shift > 0) ; stats = (sum d, sum d*xhat)
-    static constexpr bool STATS = true;
-    OT* C; long ldc; const YT* Y; long ldy;
-    const float* scale; const float* shift; const float* mean; const float* rstd;
-    const uint8_t* mask; long ldm; float inv_keep;
-    float* part1; float* part2; long ldp;
-    struct Col { float sc, sh, mu, rs; };
-    __device__ __forceinline__ Col col(int c) const { return Col{scale[c], shift[c], mean[c], rstd[c]}; }
-    __device__ __forceinline__ void apply(int row, int c, float v, const Col& cc, float& s1, float& s2) const {
-        float y = to_f32(Y[(long)row * ldy + c]);
-        float keep = mask ? (mask[(long)row * ldm + c] ? inv_keep : 0.f) : 1.f;
-        float d = (y * cc.sc + cc.sh > 0.f) ? v * keep : 0.f;
-        OT o = from_f32<OT>(d);
-        C[(long)row * ldc + c] = o;
-        float dr = to_f32(o);
-        s1 += dr; s2 += dr * (y - cc.mu) * cc.rs;
-    }
-};
 
 // ------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+constexpr int NT_STAGE_BYTES = 3 * TILE * ROW_BYTES;    // 48 KiB: main loop uses 32 (A,W); epilogue up to 32 + 16 (mask)
 
 template <typename CT, typename Src, typename Epi>
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -93,11 +38,13 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     constexpr int EPC = Mma<CT>::EPC;
     constexpr int BK = ROW_BYTES / (int)sizeof(CT);
     typedef typename Mma<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * ROW_BYTES + 4096 + 2048];
+    typedef typename Epi::out_t OT;
+    typedef typename Epi::h_t HT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NT_STAGE_BYTES + 4096 + 2048];
     unsigned char* sA = smem;
     unsigned char* sB = smem + TILE * ROW_BYTES;
-    float* aux = (float*)(smem + 2 * TILE * ROW_BYTES);
-    float* red = (float*)(smem + 2 * TILE * ROW_BYTES + 4096);
+    float* aux = (float*)(smem + NT_STAGE_BYTES);
+    float* red = (float*)(smem + NT_STAGE_BYTES + 4096);
 
     // XCD-aware tile assignment: linear id L runs on XCD L%8 (round-robin dispatch, speed only).
     const int L = blockIdx.x;
@@ -162,38 +109,15 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         __syncthreads();
     }
 
-    // epilogue
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int c = col0 + wc * 64 + n * 16 + (lane & 15);
-        if (c < N) {
-            typename Epi::Col cc = epi.col(c);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = row0 + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
-                    if (r < M) epi.apply(r, c, acc[m][n][j], cc, s1[n], s2[n]);
-                }
-        }
-    }
-    if (Epi::STATS) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s1[n] += __shfl_xor(s1[n], 16, 64); s1[n] += __shfl_xor(s1[n], 32, 64);
-            s2[n] += __shfl_xor(s2[n], 16, 64); s2[n] += __shfl_xor(s2[n], 32, 64);
-            if (lane < 16) {
-                red[(wr * 2 + 0) * TILE + wc * 64 + n * 16 + lane] = s1[n];
-                red[(wr * 2 + 1) * TILE + wc * 64 + n * 16 + lane] = s2[n];
-            }
-        }
-        __syncthreads();
-        if (tid < TILE && col0 + tid < N) {
-            if (epi.part1) epi.part1[(long)rt * epi.ldp + col0 + tid] = red[0 * TILE + tid] + red[2 * TILE + tid];
-            if (epi.part2) epi.part2[(long)rt * epi.ldp + col0 + tid] = red[1 * TILE + tid] + red[3 * TILE + tid];
-        }
-    }
+    nt_epilogue<CT>(smem, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+}
+
+struct RingSrc { const void* a; long lda; };     // tag: plain bf16 A served by the LDS-ring kernel (gemm_ring.h)
+
+template <typename CT, typename Epi>
+static int launch_nt(const RingSrc& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    if constexpr (sizeof(CT) == 2) return launch_nt_ring(src.a, src.lda, W, ldw, M, N, K, epi, st);
+    return MMVAE_ERR_DTYPE;
 }
 
 template <typename CT, typename Src, typename Epi>
@@ -210,36 +134,44 @@ template <typename CT, typename Src>
 static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t st) {
     const bool out_lp = a->c_dtype == MMVAE_BF16;
     if (a->prec == MMVAE_PREC_F32 && out_lp) return MMVAE_ERR_DTYPE;
-    typedef CT LP;   // low-precision activation type of this precision mode
+    typedef CT LP;   // activation type of this precision mode
     switch (a->epilogue) {
     case MMVAE_EPI_STORE: {
-        const bool stats = a->part1 != nullptr || a->part2 != nullptr;
+        const bool stats = a->stat1 != nullptr || a->stat2 != nullptr;
         if (a->c_dtype == MMVAE_F32) {
-            if (stats) { EpiStore<float, true> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, a->part1, a->part2, a->ldp};
+            if (stats) { EpiStore<float, true> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, 0, nullptr, 0, a->stat1, a->stat2};
                          return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st); }
-            EpiStore<float, false> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, nullptr, 0};
+            EpiStore<float, false> e{(float*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, 0, nullptr, 0, nullptr, nullptr};
             return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
-        } else {
-            if constexpr (sizeof(CT) == 2) {
-                if (stats) { EpiStore<bf16, true> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, a->part1, a->part2, a->ldp};
-                             return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st); }
-                EpiStore<bf16, false> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, nullptr, 0};
-                return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
-            }
-            return MMVAE_ERR_DTYPE;
         }
+        if constexpr (sizeof(CT) == 2) {
+            if (a->ldc % 8 || ((uintptr_t)a->c & 15)) return MMVAE_ERR_ARG;
+            if (stats) { EpiStore<bf16, true> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, 0, nullptr, 0, a->stat1, a->stat2};
+                         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st); }
+            EpiStore<bf16, false> e{(bf16*)a->c, a->ldc, a->bias, a->act, a->accumulate, nullptr, 0, nullptr, 0, nullptr, nullptr};
+            return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
+        }
+        return MMVAE_ERR_DTYPE;
     }
     case MMVAE_EPI_RELU_MASK: {     // C and H are activation-typed (bf16 in bf16 mode, f32 in f32 mode)
         if (a->h == nullptr) return MMVAE_ERR_ARG;
         if ((a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
-        EpiReluMask<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->part1, a->part2, a->ldp};
+        if (sizeof(LP) == 2 && (a->ldc % 8 || a->ldh % 8 || ((uintptr_t)a->c & 15) || ((uintptr_t)a->h & 15))) return MMVAE_ERR_ARG;
+        EpiReluMask<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, nullptr, 0, nullptr, nullptr};
         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
     }
     case MMVAE_EPI_BN_BWD: {
         if (a->h == nullptr || !a->bn_scale || !a->bn_shift || !a->bn_mean || !a->bn_rstd) return MMVAE_ERR_ARG;
-        if ((a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
-        EpiBnBwd<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd,
-                           a->epi_mask, a->ld_epi_mask, a->epi_inv_keep, a->part1, a->part2, a->ldp};
+        if (a->bn_phase == 0 ? (!a->stat1 || !a->stat2) : (!a->bn_coef || !a->c)) return MMVAE_ERR_ARG;
+        if (a->bn_phase && (a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
+        if (sizeof(LP) == 2) {
+            if (a->ldh % 8 || ((uintptr_t)a->h & 15)) return MMVAE_ERR_ARG;
+            if (a->bn_phase && (a->ldc % 8 || ((uintptr_t)a->c & 15))) return MMVAE_ERR_ARG;
+            if (a->epi_mask && (a->N % 16 || a->ld_epi_mask % 16 || ((uintptr_t)a->epi_mask & 15))) return MMVAE_ERR_ARG;
+        }
+        EpiBnBwd<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->epi_mask, a->ld_epi_mask,
+                           a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd, a->epi_inv_keep, a->bn_coef, a->bn_phase,
+                           a->bn_phase ? nullptr : a->stat1, a->bn_phase ? nullptr : a->stat2};
         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
     }
     }
@@ -260,6 +192,7 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
     if (a->a_dtype == MMVAE_BF16) {
         if constexpr (sizeof(CT) == 2) {
             if (a->lda % 8 || ((uintptr_t)a->a & 15)) return MMVAE_ERR_ARG;
+            if (ring_ok(a->a, a->lda, a->M)) { RingSrc s{a->a, a->lda}; return dispatch_epi<CT>(a, s, st); }
             SrcPlain<CT, bf16, 8> s{(const bf16*)a->a, a->lda, a->M, a->K};
             return dispatch_epi<CT>(a, s, st);
         }
@@ -282,7 +215,7 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
 }  // namespace mm
 
 extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
-    if (!a || !a->a || !a->w || !a->c) return MMVAE_ERR_ARG;
+    if (!a || !a->a || !a->w || (!a->c && !(a->epilogue == MMVAE_EPI_BN_BWD && a->bn_phase == 0))) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
     if (a->ldw % 64 || ((uintptr_t)a->w & 15)) return MMVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;

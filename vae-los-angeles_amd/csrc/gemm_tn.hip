@@ -17,6 +17,7 @@
 #include "common.h"
 #include "mmvae_hip.h"
 #include "gemm_src.h"
+#include "gemm_ring.h"
 
 namespace mm {
 
@@ -166,21 +167,145 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     }
 }
 
-template <typename CT, typename PSrc, typename QSrc>
-static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs, hipStream_t st) {
-    typedef TnGeom<CT> G;
-    const int ntn = (a->N + TILE - 1) / TILE, ntk = (a->K + TILE - 1) / TILE, ntiles = ntn * ntk;
-    int nsplit = a->nsplit;
+// ------------------------------------------------------------------------------------------
+// LDS-ring variant for plain bf16 operands (see gemm_ring.h): P and Q tiles ([64 m][128 cols] bf16,
+// 16 KiB each) are DMA'd straight into a 4-stage ring; the tr16 swizzle goes on the source address.
+// Rows past M read as zeros through the buffer resource; columns past N / K only feed accumulators
+// that are never stored.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 1)
+void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes, const bf16* __restrict__ Q, long ldq, unsigned q_bytes,
+                         float* __restrict__ dW, long ldw, float* __restrict__ db,
+                         int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split)
+{
+    typedef TnGeom<bf16> G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = blockIdx.x, slot = L >> 3;
+    const int tile = slot % ntiles;
+    const int zz = (slot / ntiles) * 8 + (L & 7);
+    if (zz >= nsplit) return;
+    const int tn = tile / ntk, tk = tile % ntk;
+    const int n0 = tn * TILE, k0 = tk * TILE;
+    const int m_begin = zz * rows_per_split;              // multiple of 64: only the global tail is ragged
+    const int m_end = min(M, m_begin + rows_per_split);
+    if (m_begin >= m_end) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+
+    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, q_bytes, 0x00020000);
+    // piece p (1 KiB) = tile rows 4p..4p+3 (256-byte rows); lane -> row 4p + (lane>>4), physical chunk lane&15,
+    // holding logical chunk (((phys>>1) ^ f(row)) << 1) | (phys & 1)   (inverse of TnGeom::chunk_off)
+    unsigned p_off[4], q_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (wid + 4 * i) + (lane >> 4), ph = lane & 15;
+        const int ch = ((((ph >> 1) ^ G::f(r)) << 1) | (ph & 1));
+        p_off[i] = (unsigned)(((long)(m_begin + r) * ldp + n0 + ch * 8) * 2);
+        q_off[i] = (unsigned)(((long)(m_begin + r) * ldq + k0 + ch * 8) * 2);
+    }
+    const unsigned p_step = (unsigned)(64 * ldp * 2), q_step = (unsigned)(64 * ldq * 2);
+    auto issue = [&](int t) {
+        unsigned char* st = smem + (t % RING_NS) * RING_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wid + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void*)(st + p * 1024), 16, p_off[i] + t * p_step, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(st + 16384 + p * 1024), 16, q_off[i] + t * q_step, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = (db != nullptr) && tk == 0 && tid < TILE;
+    const int nt = (m_end - m_begin + G::MT - 1) / G::MT;
+
+#pragma unroll
+    for (int s = 0; s < RING_NS - 1; ++s) if (s < nt) issue(s);
+    for (int t = 0; t < nt; ++t) {
+        ring_wait(min(RING_NS - 2, nt - 1 - t));
+        ring_barrier();
+        if (t + RING_NS - 1 < nt) issue(t + RING_NS - 1);
+        const unsigned char* sP = smem + (t % RING_NS) * RING_STAGE;
+        const unsigned char* sQ = sP + 16384;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = tn_frag(sP, wr * 64 + a * 16, s, lane, (bf16*)nullptr);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bfr[b] = tn_frag(sQ, wc * 64 + b * 16, s, lane, (bf16*)nullptr);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Mma<bf16>::mma(acc[a][b], af[a], bfr[b]);
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < G::MT; ++r) bsum += to_f32(*(const bf16*)(sP + G::elem_off(r, tid)));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wr * 64 + a * 16 + (lane >> 4) * 4 + j;
+            if (n >= N) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = k0 + wc * 64 + b * 16 + (lane & 15);
+                if (k < K) unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
+            }
+        }
+    if (do_bias && n0 + tid < N) unsafeAtomicAdd(db + n0 + tid, bsum);
+}
+
+static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int& ntiles, int& nsplit, int& rps) {
+    const int ntn = (N + TILE - 1) / TILE;
+    ntk = (K + TILE - 1) / TILE; ntiles = ntn * ntk;
+    nsplit = nsplit_req;
     if (nsplit <= 0) {
-        // aim for ~4 workgroups per CU in total, at least 4 m-tiles of work per workgroup
-        nsplit = (1024 + ntiles - 1) / ntiles;
-        int max_split = (a->M + 4 * G::MT - 1) / (4 * G::MT);
+        // aim for ~2 workgroups per CU in total (every split adds one f32 atomic per output element),
+        // at least 4 m-tiles of work per workgroup
+        nsplit = (512 + ntiles - 1) / ntiles;
+        int max_split = (M + 4 * MT - 1) / (4 * MT);
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     }
-    int rps = (a->M + nsplit - 1) / nsplit;
-    rps = ((rps + G::MT - 1) / G::MT) * G::MT;
-    nsplit = (a->M + rps - 1) / rps;
+    rps = (M + nsplit - 1) / nsplit;
+    rps = ((rps + MT - 1) / MT) * MT;
+    nsplit = (M + rps - 1) / rps;
+}
+
+static int launch_tn_ring(const mmvae_gemm_tn_args* a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    int ntk, ntiles, nsplit, rps;
+    tn_split(a->M, a->N, a->K, 64, a->nsplit, ntk, ntiles, nsplit, rps);
+    const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
+    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(grid), dim3(NTHREADS), RING_LDS, st,
+                       (const bf16*)a->p, a->ldp, (unsigned)((long)a->M * a->ldp * 2), (const bf16*)a->q, a->ldq,
+                       (unsigned)((long)a->M * a->ldq * 2), a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename CT, typename PSrc, typename QSrc>
+static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs, hipStream_t st) {
+    typedef TnGeom<CT> G;
+    int ntk, ntiles, nsplit, rps;
+    tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
     hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), 0, st, ps, qs,
                        a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, 1);
@@ -236,7 +361,12 @@ extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (!a || !a->p || !a->q || !a->dw) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (a->prec == MMVAE_PREC_BF16) return mm::tn_dispatch_p<mm::bf16>(a, st);
+    if (a->prec == MMVAE_PREC_BF16) {
+        if (a->p_dtype == MMVAE_BF16 && a->q_dtype == MMVAE_BF16 && a->q_prologue == MMVAE_PRO_NONE &&
+            mm::ring_ok(a->p, a->ldp, a->M) && mm::ring_ok(a->q, a->ldq, a->M))
+            return mm::launch_tn_ring(a, st);
+        return mm::tn_dispatch_p<mm::bf16>(a, st);
+    }
     if (a->prec == MMVAE_PREC_F32) return mm::tn_dispatch_p<float>(a, st);
     return MMVAE_ERR_ARG;
 }

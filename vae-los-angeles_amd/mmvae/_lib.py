@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -38,7 +38,8 @@ class GemmNtArgs(C.Structure):
                 ("h", vp), ("ldh", i64),
                 ("bn_scale", vp), ("bn_shift", vp), ("bn_mean", vp), ("bn_rstd", vp),
                 ("epi_mask", vp), ("ld_epi_mask", i64), ("epi_inv_keep", f32),
-                ("part1", vp), ("part2", vp), ("ldp", i64)]
+                ("bn_coef", vp), ("bn_phase", i32),
+                ("stat1", vp), ("stat2", vp)]
 
 
 class GemmTnArgs(C.Structure):
@@ -52,14 +53,14 @@ class GemmTnArgs(C.Structure):
 
 
 class BnFinalizeArgs(C.Structure):
-    _fields_ = [("M", i32), ("N", i32), ("n_tiles", i32), ("part_sum", vp), ("part_sumsq", vp), ("ldp", i64),
+    _fields_ = [("M", i32), ("N", i32), ("sum", vp), ("sumsq", vp),
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("momentum", f32),
                 ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
                 ("mean", vp), ("rstd", vp), ("scale", vp), ("shift", vp)]
 
 
 class BnBwdFinalizeArgs(C.Structure):
-    _fields_ = [("M", i32), ("N", i32), ("n_tiles", i32), ("part_d", vp), ("part_dx", vp), ("ldp", i64),
+    _fields_ = [("M", i32), ("N", i32), ("sum_d", vp), ("sum_dx", vp),
                 ("gamma", vp), ("rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp)]
 
 
@@ -105,12 +106,12 @@ _SIGNATURES = {
     "mmvae_bn_finalize": [C.POINTER(BnFinalizeArgs), vp],
     "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],
-    "mmvae_bn_bwd_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp],
     "mmvae_embed_table_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "mmvae_embed_table_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mmvae_fuse_reparam_fwd": [C.POINTER(FuseFwdArgs), vp],
     "mmvae_fuse_reparam_bwd": [C.POINTER(FuseBwdArgs), vp],
     "mmvae_vae_loss": [C.POINTER(LossArgs), vp],
+    "mmvae_loss_finalize": [vp, f32, f32, vp, vp],
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
     "mmvae_dropout_mask": [vp, i64, f32, C.c_uint64, C.c_uint64, vp],

@@ -1,0 +1,392 @@
+"""Launch orchestration of the MultiModalVAE training path on one MI355X.
+
+The compute blocks mirror the reference modules (file:line in each docstring) but each is a
+short sequence of launches into libmmvae_hip.so; no torch arithmetic is used on the data path.
+Activations between GEMMs are stored in the *activation type* of the precision mode (bf16 or
+f32); BatchNorm statistics, loss sums, gradients of parameters and the optimiser are fp32.
+
+What is saved for backward per BN layer is only the PRE-BatchNorm GEMM output, the per-column
+(mean, rstd, scale, shift) and the dropout keep-mask: post-activation tensors are recomputed
+inside the consumer GEMM's operand prologue.
+"""
+import os
+
+import torch
+
+from . import ops
+from .ops import (PREC_BF16, PREC_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, EPI_RELU_MASK, EPI_BN_BWD, TILE, DROP_P,
+                  ceil_to, act_dtype)
+
+_PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
+_default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
+
+
+def set_default_precision(name):
+    """'bf16' (bf16 MFMA operands/activations, f32 accumulate) or 'fp32' (f32 MFMA)."""
+    global _default_precision
+    _default_precision = _PRECISIONS[name.lower()]
+
+
+def default_precision():
+    return _default_precision
+
+
+# --------------------------------------------------------------------------------------------
+# noise
+# --------------------------------------------------------------------------------------------
+class NoiseSource:
+    """Dropout keep-masks and eps.  Default: Philox streams on the device keyed by
+    (torch.initial_seed() + rank, running offset).  `inject` replays explicit arrays in the
+    order the reference consumes its RNG (EncoderA mask, EncoderB masks, eps): parity tests."""
+
+    def __init__(self):
+        self.offset = 0
+        self._injected = None
+
+    def inject(self, masks, eps):
+        self._injected = (list(masks), eps)
+
+    def clear(self):
+        self._injected = None
+
+    def _seed(self):
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            seed = (seed + 0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1)) & 0xFFFFFFFFFFFFFFFF
+        return seed
+
+    def mask(self, B, N, device):
+        if self._injected is not None:
+            m = self._injected[0].pop(0)
+            if tuple(m.shape) != (B, N):
+                raise ValueError(f"injected mask shape {tuple(m.shape)} != {(B, N)}")
+            return m.to(device=device, dtype=torch.uint8).contiguous()
+        m = torch.empty(B, N, dtype=torch.uint8, device=device)
+        ops.dropout_mask(m, 1.0 - DROP_P, self._seed(), self.offset)
+        self.offset += (B * N + 3) // 4
+        return m
+
+    def eps(self, B, Ld, device):
+        if self._injected is not None:
+            e = self._injected[1]
+            if tuple(e.shape) != (B, Ld):
+                raise ValueError(f"injected eps shape {tuple(e.shape)} != {(B, Ld)}")
+            return e.to(device=device, dtype=torch.float32).contiguous()
+        e = torch.empty(B, Ld, dtype=torch.float32, device=device)
+        ops.randn(e, self._seed(), self.offset)
+        self.offset += (B * Ld + 3) // 4
+        return e
+
+
+GLOBAL_NOISE = NoiseSource()
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+def _check_input(x, name, cols):
+    if x.dim() != 2 or x.shape[1] != cols:
+        raise RuntimeError(f"{name}: expected shape (B, {cols}), got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name}: the MI355X path needs CUDA/HIP tensors (got {x.device}); there is no CPU fallback")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    return x
+
+
+class BNState:
+    """Per-layer BatchNorm vectors: rows of one [4][N] fp32 buffer (mean, rstd, scale, shift)."""
+
+    def __init__(self, N, device):
+        self.buf = torch.empty(4, N, dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
+
+
+# --------------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------------
+class EncoderMLP:
+    """EncoderA / EncoderB (reference src/models/encoders.py:8-23, 26-46):
+    [Linear -> BatchNorm1d -> ReLU -> Dropout(0.1)] x n, then the fc_mu | fc_logvar heads
+    computed as ONE GEMM with N = 2*latent."""
+
+    def __init__(self, linears, bns, fc_mu, fc_logvar, name="enc"):
+        self.linears, self.bns, self.fc_mu, self.fc_logvar = list(linears), list(bns), fc_mu, fc_logvar
+        self.in_dim = self.linears[0].in_features
+        self.latent = fc_mu.out_features
+        self.name = name
+
+    def prepare(self, prec, device):
+        self.pl = [ops.PreparedLinear([l.weight], [l.bias], prec, device) for l in self.linears]
+        self.pl_heads = ops.PreparedLinear([self.fc_mu.weight, self.fc_logvar.weight],
+                                           [self.fc_mu.bias, self.fc_logvar.bias], prec, device)
+        return self.pl + [self.pl_heads]
+
+    def params(self):
+        """Order of the gradient arena (heads adjacent so that one TN GEMM writes both)."""
+        out = []
+        for l, bn in zip(self.linears, self.bns):
+            out += [l.weight, l.bias, bn.weight, bn.bias]
+        out += [self.fc_mu.weight, self.fc_logvar.weight, self.fc_mu.bias, self.fc_logvar.bias]
+        return out
+
+    def forward(self, prec, x, train, noise):
+        B, dev = x.shape[0], x.device
+        adt = act_dtype(prec)
+        saved = []
+        h, pro = x, None
+        nt = (B + TILE - 1) // TILE
+        for lin, bn, pl in zip(self.linears, self.bns, self.pl):
+            N, K = pl.N, pl.K
+            y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
+            st = BNState(N, dev)
+            if train:
+                stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+                ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd")
+                ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
+                                bn.momentum if bn.momentum is not None else 0.1)
+                mask = noise.mask(B, N, dev)
+                new_pro = (st.scale, st.shift, mask, 1.0 / (1.0 - DROP_P))
+            else:
+                ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, tag=f"{self.name}.L{len(saved)}.fwd")
+                ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, st.scale, st.shift, bn.eps)
+                new_pro = (st.scale, st.shift, None, 1.0)
+            saved.append((h, pro, y, st, new_pro))
+            h, pro = y, new_pro
+        heads = torch.empty(B, 2 * self.latent, dtype=torch.float32, device=dev)
+        ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
+        return heads, saved
+
+    def backward(self, prec, saved, d_heads, grads):
+        """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated)."""
+        B, dev = d_heads.shape[0], d_heads.device
+        adt = act_dtype(prec)
+        nt = (B + TILE - 1) // TILE
+        L2 = 2 * self.latent
+        h_in, pro_in, y, st, pro = saved[-1]
+        Kl = self.pl_heads.K
+        gw = grads[self.fc_mu.weight]            # fc_logvar.weight follows immediately in the arena
+        gb = grads[self.fc_mu.bias]
+        ops.gemm_tn(prec, d_heads, y, _span(gw, L2 * Kl).view(L2, Kl), _span(gb, L2), L2, Kl, q_prologue=pro, tag=f"{self.name}.heads.dW")
+        # gradient entering the last hidden layer: dX GEMM of the heads (A = d_heads, W = heads^T)
+        src, src_wt, src_n, src_k = d_heads, self.pl_heads.wt, Kl, L2
+        for i in reversed(range(len(self.linears))):
+            lin, bn, pl = self.linears[i], self.bns[i], self.pl[i]
+            h_in, pro_in, y, st, pro = saved[i]
+            N, K = pl.N, pl.K
+            bnargs = (st.scale, st.shift, st.mean, st.rstd, pro[2], pro[3])
+            # BatchNorm/ReLU/Dropout backward of layer i as two passes over the same contraction
+            stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+            ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
+            coef = torch.empty(3, N, dtype=torch.float32, device=dev)
+            ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+            d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
+            ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
+            ops.gemm_tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
+            src, src_wt, src_n, src_k = d, pl.wt, K, N
+
+
+def _span(t, n):
+    """View of n contiguous fp32 elements starting at tensor t (inside the gradient arena)."""
+    return torch.as_strided(t, (n,), (1,))
+
+
+class EmbedEncoder:
+    """EncoderC (encoders.py:49-61): Embedding(S,E) + two heads == a [S][2L] table + gather."""
+
+    def __init__(self, embedding, fc_mu, fc_logvar):
+        self.embedding, self.fc_mu, self.fc_logvar = embedding, fc_mu, fc_logvar
+        self.latent = fc_mu.out_features
+
+    def prepare(self, prec, device):
+        return []
+
+    def params(self):
+        return [self.embedding.weight, self.fc_mu.weight, self.fc_mu.bias, self.fc_logvar.weight, self.fc_logvar.bias]
+
+    def table(self):
+        emb = self.embedding.weight
+        t = torch.empty(emb.shape[0], 2 * self.latent, dtype=torch.float32, device=emb.device)
+        ops.embed_table_fwd(emb, self.fc_mu.weight, self.fc_mu.bias, self.fc_logvar.weight, self.fc_logvar.bias, t)
+        return t
+
+    def backward(self, d_table, grads):
+        ops.embed_table_bwd(self.embedding.weight, self.fc_mu.weight, self.fc_logvar.weight, d_table,
+                            grads[self.embedding.weight], grads[self.fc_mu.weight], grads[self.fc_mu.bias],
+                            grads[self.fc_logvar.weight], grads[self.fc_logvar.bias])
+
+
+class DecoderMLP:
+    """DecoderA/B/C (src/models/decoders.py:8-50): Linear(+ReLU) chain, optional final Sigmoid.
+    Hidden activations are stored in the activation type, the output in fp32 (it is returned
+    to the caller)."""
+
+    def __init__(self, linears, final_sigmoid, name="dec"):
+        self.linears, self.final_sigmoid = list(linears), final_sigmoid
+        self.out_dim = self.linears[-1].out_features
+        self.name = name
+
+    def prepare(self, prec, device):
+        self.pl = [ops.PreparedLinear([l.weight], [l.bias], prec, device) for l in self.linears]
+        return self.pl
+
+    def params(self):
+        out = []
+        for l in self.linears:
+            out += [l.weight, l.bias]
+        return out
+
+    def forward(self, prec, z):
+        B, dev = z.shape[0], z.device
+        adt = act_dtype(prec)
+        acts = [z]
+        h = z
+        for j, pl in enumerate(self.pl):
+            last = j == len(self.pl) - 1
+            if last:
+                out = torch.empty(B, pl.N, dtype=torch.float32, device=dev)
+                ops.gemm_nt(prec, h, pl.w, pl.N, pl.K, out, bias=pl.bias, act=ACT_SIGMOID if self.final_sigmoid else ACT_NONE, tag=f"{self.name}.L{j}.fwd")
+            else:
+                out = torch.empty(B, ceil_to(pl.N, 8), dtype=adt, device=dev)
+                ops.gemm_nt(prec, h, pl.w, pl.N, pl.K, out, bias=pl.bias, act=ACT_RELU, tag=f"{self.name}.L{j}.fwd")
+                acts.append(out)
+            h = out
+        return h, acts
+
+    def backward(self, prec, acts, out, g_out, g_is_logit_grad, dz, accumulate_dz, grads):
+        """g_out: gradient w.r.t. the decoder output ([B][>=N], fp32 or activation type).  For a
+        sigmoid decoder it is w.r.t. the pre-sigmoid logits iff g_is_logit_grad."""
+        B, dev = dz.shape[0], dz.device
+        adt = act_dtype(prec)
+        d = g_out
+        if self.final_sigmoid and not g_is_logit_grad:
+            dl = torch.empty(B, ceil_to(self.out_dim, 8), dtype=adt, device=dev)
+            ops.sigmoid_bwd(g_out, out, dl)
+            d = dl
+        for j in reversed(range(len(self.pl))):
+            pl, lin = self.pl[j], self.linears[j]
+            ops.gemm_tn(prec, d, acts[j], grads[lin.weight], grads[lin.bias], pl.N, pl.K, tag=f"{self.name}.L{j}.dW")
+            if j > 0:
+                d_prev = torch.empty(B, ceil_to(pl.K, 8), dtype=adt, device=dev)
+                ops.gemm_nt(prec, d, pl.wt, pl.K, pl.N, d_prev, epilogue=EPI_RELU_MASK, h=acts[j], tag=f"{self.name}.L{j}.dX")
+                d = d_prev
+            else:
+                ops.gemm_nt(prec, d, pl.wt, pl.K, pl.N, dz, accumulate=accumulate_dz, tag=f"{self.name}.L{j}.dX")
+
+
+# --------------------------------------------------------------------------------------------
+# a VAE graph: encoders -> mean-fusion -> reparameterise -> decoders
+# --------------------------------------------------------------------------------------------
+class VAEGraph:
+    """Compute graph shared by MultiModalVAE (vae.py:18-79), RNA2DNAVAE and DNA2RNAVAE
+    (directional_vae.py:12-111): any subset of {MLP encoder a, MLP encoder b, embedding
+    encoder}, mean fusion, reparameterisation, and a list of decoders."""
+
+    def __init__(self, enc_a=None, enc_b=None, enc_c=None, decoders=()):
+        self.enc_a, self.enc_b, self.enc_c = enc_a, enc_b, enc_c
+        self.decoders = list(decoders)
+        self.blocks = [b for b in (enc_a, enc_b, enc_c) if b is not None] + self.decoders
+        self.latent = (enc_a or enc_b or enc_c).latent
+        self._prep = None
+        self._prep_key = None
+        self.noise = GLOBAL_NOISE
+        self.grad_sync = None          # mmvae.parallel.GradAllReduce (early/final hooks) under data parallelism
+
+    def param_list(self):
+        out = []
+        for b in self.blocks:
+            out += b.params()
+        return out
+
+    def _ensure_prepared(self, prec, device):
+        key = (prec, str(device)) + tuple(p.data_ptr() for p in self.param_list())
+        if self._prep is None or self._prep_key != key:
+            pls = []
+            for b in self.blocks:
+                pls += b.prepare(prec, device)
+            self._prep = ops.WeightPrep(pls, device)
+            self._prep_key = key
+        self._prep.run()
+
+    def forward(self, prec, xa, xb, site, train):
+        """Returns (outs(list, fp32), mu, logvar, saved)."""
+        ref = xa if xa is not None else (xb if xb is not None else site)
+        dev, B = ref.device, ref.shape[0]
+        if not ref.is_cuda or any(p.device != dev for p in self.param_list()):
+            raise RuntimeError(f"the MI355X path needs inputs and parameters on one CUDA/HIP device (input on {dev}); "
+                               "there is no CPU fallback")
+        self._ensure_prepared(prec, dev)
+        saved = {"prec": prec, "B": B, "train": train}
+        heads_a = heads_b = table = None
+        if xa is not None:
+            xa = _check_input(xa, "a", self.enc_a.in_dim)
+            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, self.noise)
+        if xb is not None:
+            xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
+            heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, self.noise)
+        if site is not None:
+            if site.dtype != torch.int64:
+                site = site.long()
+            site = site.contiguous()
+            table = self.enc_c.table()
+            saved["site"] = site
+        Ld = self.latent
+        eps = self.noise.eps(B, Ld, dev)
+        mu = torch.empty(B, Ld, dtype=torch.float32, device=dev)
+        logvar = torch.empty(B, Ld, dtype=torch.float32, device=dev)
+        z = torch.empty(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=dev)
+        ops.fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z)
+        saved.update(eps=eps, logvar=logvar, n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
+        outs, saved["dec"] = [], []
+        for dec in self.decoders:
+            o, acts = dec.forward(prec, z)
+            outs.append(o)
+            saved["dec"].append((acts, o))
+        return outs, mu, logvar, saved
+
+    def alloc_grads(self, device):
+        params = self.param_list()
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        views, off = {}, 0
+        for p in params:
+            views[p] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        return flat, views
+
+    def backward(self, saved, g_outs, g_logit_flags, g_mu, g_lv):
+        """g_outs[i]: gradient w.r.t. decoder i's output or None; g_mu/g_lv fp32 [B][L] or None.
+        Returns (flat_arena, {param: grad view})."""
+        prec, B = saved["prec"], saved["B"]
+        dev = saved["eps"].device
+        Ld = self.latent
+        flat, grads = self.alloc_grads(dev)
+        dz = torch.zeros(B, Ld, dtype=torch.float32, device=dev)
+        first = True
+        for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):
+            if g is None:
+                continue
+            dec.backward(prec, acts, out, g, is_logit, dz, not first, grads)
+            first = False
+        if self.grad_sync is not None:
+            # decoder gradients (tail of the arena) are final: start reducing them under the encoder backward
+            self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
+        n_mod = saved["n_mod"]
+        d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
+        site = saved.get("site")
+        d_table = None
+        if site is not None:
+            d_table = torch.zeros(self.enc_c.embedding.weight.shape[0], 2 * Ld, dtype=torch.float32, device=dev)
+        ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dz, saved["eps"], saved["logvar"], d_heads, d_table, site)
+        if "enc_a" in saved:
+            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads)
+        if "enc_b" in saved:
+            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads)
+        if site is not None:
+            self.enc_c.backward(d_table, grads)
+        if self.grad_sync is not None:
+            self.grad_sync.final(flat)
+        return flat, grads

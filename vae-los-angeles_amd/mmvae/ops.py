@@ -12,6 +12,39 @@ DROP_P = 0.1                      # nn.Dropout(0.1), reference src/models/encode
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # nn.BatchNorm1d defaults, encoders.py:14,32,36
 
 
+class KernelProbe:
+    """Optional per-launch timer: HIP events recorded on the launch stream around tagged GEMM
+    launches (bench.py uses it for the live roofline numbers).  Off (None) by default."""
+
+    def __init__(self, only=None):
+        self.records = {}          # tag -> [(start_event, end_event, meta)]
+        self.only = only           # optional set of tags to time (None = all)
+
+    def wants(self, tag):
+        return tag is not None and (self.only is None or tag in self.only)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, tag, start, meta):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.setdefault(tag, []).append((start, ev, meta))
+
+    def summary(self):
+        """tag -> dict(calls, mean_ms, meta); call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            out[tag] = dict(calls=len(ms), mean_ms=sum(ms) / len(ms), meta=recs[0][2])
+        return out
+
+
+PROBE = None
+
+
 def ceil_to(x, m):
     return (x + m - 1) // m * m
 
@@ -121,10 +154,13 @@ class WeightPrep:
 # GEMMs
 # --------------------------------------------------------------------------------------------
 def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
-            epilogue=EPI_STORE, h=None, bn=None, part1=None, part2=None):
+            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, stats=None, tag=None):
     """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
-    bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD."""
-    _mat(a, "a"); _mat(out, "out"); _mat(w_lp, "w")
+    bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD (out=None, stats given:
+    statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator."""
+    _mat(a, "a"); _mat(w_lp, "w")
+    if out is not None:
+        _mat(out, "out")
     M = a.shape[0]
     g = L.GemmNtArgs()
     g.prec, g.M, g.N, g.K = prec, M, N, K
@@ -137,7 +173,8 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
         g.pro_inv_keep = inv_keep
     g.w, g.ldw = w_lp.data_ptr(), w_lp.stride(0)
     g.epilogue = epilogue
-    g.c, g.c_dtype, g.ldc = out.data_ptr(), _dt(out), _ld(out)
+    if out is not None:
+        g.c, g.c_dtype, g.ldc = out.data_ptr(), _dt(out), _ld(out)
     g.bias, g.act, g.accumulate = _p(bias), act, int(accumulate)
     if h is not None:
         g.h, g.ldh = h.data_ptr(), _ld(h)
@@ -145,15 +182,20 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
         sc, sh, mean, rstd, mask, inv_keep = bn
         g.bn_scale, g.bn_shift, g.bn_mean, g.bn_rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         g.epi_mask, g.ld_epi_mask, g.epi_inv_keep = _p(mask), (_ld(mask) if mask is not None else 0), inv_keep
-    if part1 is not None:
-        g.part1, g.ldp = part1.data_ptr(), part1.stride(0)
-    if part2 is not None:
-        g.part2, g.ldp = part2.data_ptr(), part2.stride(0)
+        g.bn_coef, g.bn_phase = _p(bn_coef), int(bn_coef is not None)
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.shape[0] == 2 and stats.shape[1] >= N and stats.stride(1) == 1
+        g.stat1, g.stat2 = stats[0].data_ptr(), stats[1].data_ptr()
+    t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_nt(C.byref(g), _stream()), "mmvae_gemm_nt")
+    if t0 is not None:
+        PROBE.end(tag, t0, dict(kind="nt", M=M, N=N, K=K, a_bytes=a.element_size(), c_bytes=0 if out is None else out.element_size(),
+                                pro=prologue is not None, pro_mask=prologue is not None and prologue[2] is not None,
+                                epi=epilogue, epi_mask=bn is not None and bn[4] is not None, act_bytes=2 if prec == PREC_BF16 else 4))
     return out
 
 
-def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0):
+def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, tag=None):
     """dw[N,K] += p[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(p).  dw/db fp32, pre-zeroed."""
     _mat(p, "p"); _mat(q, "q")
     g = L.GemmTnArgs()
@@ -169,18 +211,22 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0):
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     g.dw, g.lddw, g.db = dw.data_ptr(), K, _p(db)
     g.nsplit = nsplit
+    t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_tn(C.byref(g), _stream()), "mmvae_gemm_tn")
+    if t0 is not None:
+        PROBE.end(tag, t0, dict(kind="tn", M=p.shape[0], N=N, K=K, p_bytes=p.element_size(), q_bytes=q.element_size(),
+                                pro_mask=q_prologue is not None and q_prologue[2] is not None))
 
 
 # --------------------------------------------------------------------------------------------
 # BatchNorm pieces
 # --------------------------------------------------------------------------------------------
-def bn_finalize(M, N, part_sum, part_sumsq, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
+def bn_finalize(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
                 eps=BN_EPS, momentum=BN_MOMENTUM):
     if M < 2:
         # same failure mode as torch.nn.BatchNorm1d in training mode
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{M}, {N}]")
-    a = L.BnFinalizeArgs(M, N, part_sum.shape[0], part_sum.data_ptr(), part_sumsq.data_ptr(), part_sum.stride(0),
+    a = L.BnFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
                          gamma.data_ptr(), beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
                          mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
     L.check(L.load().mmvae_bn_finalize(C.byref(a), _stream()), "mmvae_bn_finalize")
@@ -192,15 +238,10 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift, eps=BN_
             "mmvae_bn_eval_coeffs")
 
 
-def bn_bwd_finalize(M, N, part_d, part_dx, gamma, rstd, dgamma, dbeta, coef):
-    a = L.BnBwdFinalizeArgs(M, N, part_d.shape[0], part_d.data_ptr(), part_dx.data_ptr(), part_d.stride(0),
+def bn_bwd_finalize(M, N, stats, gamma, rstd, dgamma, dbeta, coef):
+    a = L.BnBwdFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
                             gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr())
     L.check(L.load().mmvae_bn_bwd_finalize(C.byref(a), _stream()), "mmvae_bn_bwd_finalize")
-
-
-def bn_bwd_apply(d, y, N, mean, rstd, coef):
-    L.check(L.load().mmvae_bn_bwd_apply(_dt(d), d.shape[0], N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y),
-                                        mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), _stream()), "mmvae_bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------
@@ -256,6 +297,10 @@ def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site
         x.g_c, x.ld_gc = g_c.data_ptr(), _ld(g_c)
     x.g_mu, x.g_lv = _p(g_mu), _p(g_lv)
     L.check(L.load().mmvae_vae_loss(C.byref(x), _stream()), "mmvae_vae_loss")
+
+
+def loss_finalize(sums, beta, gamma, out4):
+    L.check(L.load().mmvae_loss_finalize(sums.data_ptr(), beta, gamma, out4.data_ptr(), _stream()), "mmvae_loss_finalize")
 
 
 def sigmoid_bwd(g, p, out):
