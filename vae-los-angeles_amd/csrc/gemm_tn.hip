@@ -92,8 +92,8 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const bool do_bias = (db != nullptr) && tk == 0 && tid < TILE;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (db != nullptr) && tk == 0 && wc == 0;     // wave-uniform
 
     typename PSrc::Raw rp[4];
     typename QSrc::Raw rq[4];
@@ -139,10 +139,12 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) Mma<CT>::mma(acc[a][b], af[a], bf[b]);
-        }
-        if (do_bias) {
-#pragma unroll 8
-            for (int r = 0; r < G::MT; ++r) bsum += to_f32(*(const CT*)(sP + G::elem_off(r, tid)));
+            if (do_bias) {                      // column sums of P straight from the A fragments (VALU is idle here)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < Mma<CT>::EPC; ++j) bsum[a] += to_f32(af[a][j]);
+            }
         }
         __syncthreads();
     }
@@ -162,8 +164,14 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
                 }
             }
         }
-    if (do_bias && n0 + tid < N) {
-        if (use_atomic) unsafeAtomicAdd(db + n0 + tid, bsum); else db[n0 + tid] += bsum;
+    if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wr * 64 + a * 16 + lane;
+            if (lane < 16 && n < N) unsafeAtomicAdd(db + n, v);
+        }
     }
 }
 
@@ -221,8 +229,8 @@ void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes,
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const bool do_bias = (db != nullptr) && tk == 0 && tid < TILE;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (db != nullptr) && tk == 0 && wc == 0;
     const int nt = (m_end - m_begin + G::MT - 1) / G::MT;
 
 #pragma unroll
@@ -244,10 +252,12 @@ void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes,
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) Mma<bf16>::mma(acc[a][b], af[a], bfr[b]);
-        }
-        if (do_bias) {
-#pragma unroll 8
-            for (int r = 0; r < G::MT; ++r) bsum += to_f32(*(const bf16*)(sP + G::elem_off(r, tid)));
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[a] += to_f32(af[a][j]);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,7 +274,15 @@ void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes,
                 if (k < K) unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
             }
         }
-    if (do_bias && n0 + tid < N) unsafeAtomicAdd(db + n0 + tid, bsum);
+    if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wr * 64 + a * 16 + lane;
+            if (lane < 16 && n < N) unsafeAtomicAdd(db + n, v);
+        }
+    }
 }
 
 static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int& ntiles, int& nsplit, int& rps) {
