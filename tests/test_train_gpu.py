@@ -1,0 +1,100 @@
+"""End-to-end training behaviour on the GPU: multi-step loss trajectory against the numpy oracle
+(same injected noise every step), Philox-noise training making progress in bf16, checkpoint
+round trip, and the reference-shaped train.py harness."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import np_oracle as O  # noqa: E402
+from model_util import load_state, masks_list, f64  # noqa: E402
+from mmvae import engine  # noqa: E402
+from mmvae.optim import FusedAdamW  # noqa: E402
+from src.models import MultiModalVAE  # noqa: E402
+from src.utils import vae_loss  # noqa: E402
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 4e-3)])
+def test_loss_trajectory_vs_oracle(prec, tol):
+    """8 AdamW steps on one batch (B=512, default dims): per-step total loss within `tol` relative of the
+    fp64 oracle.  lr is raised to 5e-3 so that the parameters actually move."""
+    A, D, S, L, E, B, steps = 782, 572, 24, 20, 32, 512, 8
+    P, Bf = O.make_params(77, A, D, S, L, E)
+    a, b, site = O.make_batch(78, B, A, D, S)
+    P64, Bf64 = f64(P), f64(Bf)
+    st, step = O.adamw_init(P64)
+    model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), P, Bf).to(DEV).set_precision(prec).train()
+    opt = FusedAdamW(model.parameters(), lr=5e-3, weight_decay=1e-5)
+    ta, tb, ts = (torch.from_numpy(x).to(DEV) for x in (a, b, site))
+    ref_losses, got_losses = [], []
+    for s in range(steps):
+        masks, eps = O.make_noise(1000 + s, B, L)
+        r = O.train_step(P64, Bf64, st, step, a.astype(np.float64), b.astype(np.float64), site, masks, eps.astype(np.float64),
+                         beta=1e-3, gamma=1.0, lr=5e-3, wd=1e-5)
+        step = r["step"]
+        ref_losses.append(r["total"])
+        engine.GLOBAL_NOISE.inject(masks_list(masks), torch.from_numpy(eps))
+        ra, rb, rc, mu, lv = model(a=ta, b=tb, site=ts)
+        loss, *_ = vae_loss(ra, ta, rb, tb, rc, ts, mu, lv)
+        engine.GLOBAL_NOISE.clear()
+        opt.zero_grad(); loss.backward(); opt.step()
+        got_losses.append(loss.item())
+    ref_losses, got_losses = np.array(ref_losses), np.array(got_losses)
+    assert ref_losses[-1] < 0.9 * ref_losses[0]                       # the oracle itself is learning
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=tol)
+
+
+def test_philox_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):
+    torch.manual_seed(0)
+    A, D, S, L, B = 782, 572, 24, 20, 2048
+    model = MultiModalVAE(A, D, S, L).to(DEV).train()                 # default precision: bf16
+    opt = FusedAdamW(model.parameters(), lr=2e-3, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(B, A, generator=g).abs().to(DEV); b = torch.rand(B, D, generator=g).to(DEV)
+    site = torch.randint(0, S, (B,), generator=g).to(DEV)
+    losses = []
+    for _ in range(40):
+        ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+        loss, rec, cls, kld = vae_loss(ra, a, rb, b, rc, site, mu, lv)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses[::8]
+    # dropout / eps really vary between steps (Philox offset advances)
+    model.train()
+    o1 = model(a=a, b=b, site=site)[3]; o2 = model(a=a, b=b, site=site)[3]
+    assert not torch.equal(o1, o2)
+    # state_dict round trip (checkpoint ABI: train_dna2rna.py:230-231 / reconstruct_unmatched.py:66)
+    path = tmp_path / "best_multivae.pt"
+    torch.save(model.state_dict(), path)
+    m2 = MultiModalVAE(A, D, S, L)
+    m2.load_state_dict(torch.load(path, weights_only=True))
+    m2.to(DEV).eval(); model.eval()
+    eps = torch.randn(B, L)
+    with torch.no_grad():
+        engine.GLOBAL_NOISE.inject([], eps); r1 = model(a=a, b=b, site=site)
+        engine.GLOBAL_NOISE.inject([], eps); r2 = m2(a=a, b=b, site=site)
+        engine.GLOBAL_NOISE.clear()
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    sd = FusedAdamW(m2.parameters()).state_dict()                    # optimiser state layout = torch.optim.AdamW's
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["betas"] == (0.9, 0.999)
+
+
+def test_train_py_harness(tmp_path):
+    env = dict(os.environ, PYTHONPATH="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "vae-los-angeles_amd", "train.py"), "--samples", "8192", "--batch-size", "1024",
+                          "--epochs", "2", "--checkpoint-dir", str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Epoch [2/2]" in out.stdout and "Training complete" in out.stdout
+    ck = [f for f in os.listdir(tmp_path) if f.startswith("best_multivae_")]
+    assert len(ck) == 1
+    sd = torch.load(os.path.join(tmp_path, ck[0]), weights_only=True)
+    assert "encoder_b.fc.5.running_var" in sd and sd["decoder_a.fc.2.weight"].shape == (782, 128)
