@@ -56,6 +56,17 @@ def launch_bytes_flops(meta):
     return byts, 2.0 * M * N * K
 
 
+def pmc_traffic(tag, B):
+    """HBM bytes per launch of `tag` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json, collected at
+    B=65536 with tools/run_dominant.py as MI355X_MICROARCH.md prescribes); None when that launch was not profiled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files or B != 65536:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(tag)
+    return None if k is None else k["total_bytes"]
+
+
 def cpu_baseline(B, steps):
     import torch_ref
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("MMVAE_CPU_THREADS", "16"))))   # the box grants a 16-CPU share per GPU
@@ -181,11 +192,11 @@ def main():
             t_mfma = dom["flops"] / (MFMA_PEAK_TFLOPS[args.precision] * 1e12)
             if t_hbm >= t_mfma:
                 out["roofline"] = {"bound": "hbm", "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["tag"],
+                                   "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["tag"], B), "kernel": dom["tag"],
                                    "launch_ms": dom["ms"], "algorithmic_bytes": dom["bytes"]}
             else:
                 out["roofline"] = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": MFMA_PEAK_TFLOPS[args.precision],
-                                   "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": None,
+                                   "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": pmc_traffic(dom["tag"], B),
                                    "kernel": dom["tag"], "launch_ms": dom["ms"], "algorithmic_flops": dom["flops"]}
             out["gemm_ms_per_step"] = sum(k["per_step_ms"] for k in kernels)
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items() if k not in ("bytes", "flops")}

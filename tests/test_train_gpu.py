@@ -60,12 +60,20 @@ def test_philox_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):
     g = torch.Generator().manual_seed(5)
     a = torch.randn(B, A, generator=g).abs().to(DEV); b = torch.rand(B, D, generator=g).to(DEV)
     site = torch.randint(0, S, (B,), generator=g).to(DEV)
-    losses = []
-    for _ in range(40):
-        ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
-        loss, rec, cls, kld = vae_loss(ra, a, rb, b, rc, site, mu, lv)
-        opt.zero_grad(); loss.backward(); opt.step()
-        losses.append(loss.item())
+    losses, mem = [], []
+    import gc
+    gc.disable()                                                      # activations must be freed by refcount alone
+    try:
+        for _ in range(40):
+            ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+            loss, rec, cls, kld = vae_loss(ra, a, rb, b, rc, site, mu, lv)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+            del ra, rb, rc, mu, lv, loss
+            mem.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert mem[-1] <= mem[5] + (1 << 20), (mem[5], mem[-1])           # no per-step growth (no saved-state reference cycles)
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses[::8]
     # dropout / eps really vary between steps (Philox offset advances)
     model.train()

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Launch one hot-path GEMM shape in isolation (same shapes/dtypes as in bench.py at B=65536) so that
+rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE rows all belong to that launch:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/run_dominant.py DecoderB.L2.dW
+Inputs are > 256 MiB in total or rotated over several buffers so the Infinity Cache cannot hide re-reads."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "vae-los-angeles_amd")]
+import torch
+from mmvae import ops
+from mmvae.ops import PREC_BF16
+
+dev, M = "cuda", 65536
+tag = sys.argv[1] if len(sys.argv) > 1 else "DecoderB.L2.dW"
+reps, nbuf = 6, 4
+
+
+def bf(rows, cols):
+    return [torch.randn(rows, ops.ceil_to(cols, 8), device=dev).bfloat16() for _ in range(nbuf)]
+
+
+if tag == "DecoderB.L2.dW":            # dW[572,512] += g_b^T H2
+    P, Q = bf(M, 572), bf(M, 512)
+    dw, db = torch.zeros(572, 512, device=dev), torch.zeros(572, device=dev)
+    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 572, 512)
+elif tag == "EncoderB.L0.dW":          # dW[512,572] += dy^T b   (b fp32)
+    P = bf(M, 512); Q = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
+    dw, db = torch.zeros(512, 572, device=dev), torch.zeros(512, device=dev)
+    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 512, 572)
+elif tag == "EncoderB.L0.fwd":         # y[B,512] = b W^T (+ BN statistics)
+    A = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
+    W = torch.randn(512, 572, device=dev) / 24; bias = torch.zeros(512, device=dev)
+    pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
+    out = torch.empty(M, 512, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, 512, dtype=torch.float64, device=dev)
+    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, 512, 572, out, bias=pl.bias, stats=st)
+elif tag == "DecoderB.L2.fwd":         # recon_b[B,572] = sigmoid(H2 W^T + b), fp32 out
+    A = bf(M, 512)
+    W = torch.randn(572, 512, device=dev) / 22; bias = torch.zeros(572, device=dev)
+    pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
+    out = torch.empty(M, 572, device=dev)
+    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, 572, 512, out, bias=pl.bias, act=ops.ACT_SIGMOID)
+else:
+    raise SystemExit(f"unknown tag {tag}")
+for i in range(reps):
+    run(i)
+torch.cuda.synchronize()
+print("done", tag)

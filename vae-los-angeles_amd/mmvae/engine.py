@@ -339,12 +339,15 @@ class VAEGraph:
         logvar = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         z = torch.empty(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=dev)
         ops.fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z)
-        saved.update(eps=eps, logvar=logvar, n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
+        # .detach(): aliases of the RETURNED tensors, so the saved state holds no reference to objects that own the
+        # autograd node (tensor -> grad_fn -> ctx -> saved -> tensor would be a cycle only the cyclic GC frees,
+        # i.e. every step's activations would pile up in HBM until it runs)
+        saved.update(eps=eps, logvar=logvar.detach(), n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
         outs, saved["dec"] = [], []
         for dec in self.decoders:
             o, acts = dec.forward(prec, z)
             outs.append(o)
-            saved["dec"].append((acts, o))
+            saved["dec"].append((acts, o.detach()))
         return outs, mu, logvar, saved
 
     def alloc_grads(self, device):

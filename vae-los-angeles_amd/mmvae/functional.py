@@ -346,7 +346,7 @@ class DecoderFn(torch.autograd.Function):
         za = torch.zeros(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=z.device)
         za[:, :Ld].copy_(z)
         out, acts = blk.forward(prec, za)
-        ctx.rt, ctx.prec, ctx.acts, ctx.out, ctx.Ld = rt, prec, acts, out, Ld
+        ctx.rt, ctx.prec, ctx.acts, ctx.out, ctx.Ld = rt, prec, acts, out.detach(), Ld      # detach: no ctx <-> output cycle
         ctx.z_needs = z.requires_grad
         return out
 
