@@ -213,18 +213,25 @@ int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const float* scale_
  * encoders.py:16,34,38; replaces aten::bernoulli_) and standard normal eps
  * (torch.randn_like, vae.py:14).
  * ------------------------------------------------------------------------------------------- */
-int mmvae_dropout_mask(uint8_t* mask, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
-int mmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* One launch: n_mask keep-mask bytes (P(1) = keep_prob) and n_eps standard normals.  The Philox counter starts at
+ * offset + *offset_dev (offset_dev may be NULL); a device-resident offset advanced by mmvae_counter_add lets a captured
+ * hipGraph draw fresh noise on every replay.  The call consumes ceil(n_mask/16)*4 + ceil(n_eps/4) counter values. */
+int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed, uint64_t offset,
+                const uint64_t* offset_dev, void* stream);
+int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /* *counter_dev += inc */
 
 /* ---------------------------------------------------------------------------------------------
  * AdamW (torch.optim.AdamW, constructed by the caller: optimize_hyperparameters.py:93-97,
- * train_dna2rna.py:185-189), all tensors in one launch from a device-resident table:
+ * train_dna2rna.py:185-189), all tensors in one launch per 64 tensors.  `items_host` is an array in HOST memory
+ * (device pointers inside); it is copied into the kernel arguments, so nothing is uploaded and the call is graph-capturable:
  *   p *= 1-lr*wd ; m = b1*m+(1-b1)g ; v = b2*v+(1-b2)g^2 ; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
  * ------------------------------------------------------------------------------------------- */
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } mmvae_adamw_item;
-int mmvae_adamw_step(const mmvae_adamw_item* items_dev, int32_t n_items, int64_t max_numel, float lr, float beta1,
+int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                     void* stream);
+                     const uint64_t* step_dev, void* stream);
+/* step_dev != NULL: bias corrections are computed in the kernel from t = *step_dev + 1 (graph-capturable; advance the
+ * counter with mmvae_counter_add after the launch) and bias_corr1/2 are ignored. */
 
 #ifdef __cplusplus
 }

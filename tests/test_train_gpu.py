@@ -106,3 +106,42 @@ def test_train_py_harness(tmp_path):
     assert len(ck) == 1
     sd = torch.load(os.path.join(tmp_path, ck[0]), weights_only=True)
     assert "encoder_b.fc.5.running_var" in sd and sd["decoder_a.fc.2.weight"].shape == (782, 128)
+
+
+def test_graphed_train_step_matches_eager():
+    """hipGraph replay of the whole step == eager steps: same losses step by step (same Philox stream because the
+    offset lives on the device and both variants advance it identically), parameters equal at the end."""
+    from mmvae.graphs import GraphedTrainStep
+    A, D, S, L, B = 782, 572, 24, 20, 1024
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(B, A, generator=g).abs().to(DEV); b = torch.rand(B, D, generator=g).to(DEV)
+    site = torch.randint(0, S, (B,), generator=g).to(DEV)
+
+    def fresh():
+        torch.manual_seed(123)
+        m = MultiModalVAE(A, D, S, L).to(DEV).train()
+        engine.GLOBAL_NOISE.offset_tensor(torch.device(DEV, torch.cuda.current_device())).zero_()
+        return m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    n_warm, n_run = 3, 6
+    m1, o1 = fresh()
+    eager = []
+    for _ in range(n_warm + 1 + n_run):                  # warm-up steps + the captured (eagerly executed?) step: see below
+        ra, rb, rc, mu, lv = m1(a=a, b=b, site=site)
+        loss, *_ = vae_loss(ra, a, rb, b, rc, site, mu, lv)
+        o1.zero_grad(); loss.backward(); o1.step()
+        eager.append(loss.item())
+    m2, o2 = fresh()
+    gs = GraphedTrainStep(m2, o2, a, b, site, warmup=n_warm)       # capture does not execute: n_warm steps applied so far
+    got = []
+    for _ in range(1 + n_run):
+        gs()
+        got.append(gs.losses()[0])
+    np.testing.assert_allclose(got, eager[n_warm:], rtol=2e-3)      # bf16 + atomics order: not bitwise
+    from model_util import CHAOTIC_BIASES
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k in CHAOTIC_BIASES:
+            continue
+        d = (p1 - p2).abs()          # Adam amplifies atomics-order noise on near-zero gradients to +-lr per step
+        assert float(d.max()) <= 10 * 1e-3 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
+    assert int(o2.state[next(iter(m2.parameters()))]["step"].item()) == n_warm + 1 + n_run

@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256) void scale_if_needed_kernel(T* x, long n, cons
 // ------------------------------------------------------------------------------------------
 // noise
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, long n, uint32_t thresh, uint64_t seed, uint64_t offset) {
-    const long nq = (n + 15) / 16;                 // 16 mask bytes per thread-iteration
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+// `offset_dev` (optional) is a device-resident running offset added to `offset`: it lets a captured hipGraph draw
+// fresh noise on every replay (mmvae_counter_add advances it at the end of the step).
+__device__ __forceinline__ void mask_quad(uint8_t* mask, long n, long q, uint32_t thresh, uint64_t seed, uint64_t offset) {
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -299,12 +299,9 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, long n
         }
         if (q * 16 + 16 <= n) { uint4 v = {w[0], w[1], w[2], w[3]}; *(uint4*)(mask + q * 16) = v; }
         else for (long i = q * 16; i < n; ++i) mask[i] = (uint8_t)((w[(i - q * 16) >> 2] >> (8 * ((i - q * 16) & 3))) & 0xff);
-    }
 }
 
-__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t seed, uint64_t offset) {
-    const long nq = (n + 3) / 4;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void randn_quad(float* out, long n, long q, uint64_t seed, uint64_t offset) {
         uint32_t r[4];
         Philox::gen(seed, offset + (uint64_t)q, 0x4E4F524Dull /* "NORM" */, r);
         float z[4];
@@ -317,16 +314,37 @@ __global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t
             sincosf(6.283185307179586f * u2, &sn, &cs);
             z[2 * k] = rad * cs; z[2 * k + 1] = rad * sn;
         }
-        for (int k = 0; k < 4; ++k) if (q * 4 + k < n) out[q * 4 + k] = z[k];
+        if (q * 4 + 4 <= n && (((uintptr_t)out & 15) == 0)) *(f32x4*)(out + q * 4) = f32x4{z[0], z[1], z[2], z[3]};
+        else for (int k = 0; k < 4; ++k) if (q * 4 + k < n) out[q * 4 + k] = z[k];
+}
+
+// one launch for all dropout masks (one contiguous uint8 buffer) and eps of a forward pass
+__global__ __launch_bounds__(256) void noise_kernel(uint8_t* mask, long n_mask, float* eps, long n_eps, uint32_t thresh,
+                                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev) {
+    if (offset_dev) offset += *offset_dev;
+    const long nqm = (n_mask + 15) / 16, nqe = (n_eps + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nqm + nqe; q += (long)gridDim.x * blockDim.x) {
+        if (q < nqm) mask_quad(mask, n_mask, q, thresh, seed, offset);
+        else randn_quad(eps, n_eps, q - nqm, seed, offset + (uint64_t)nqm * 4);
     }
 }
+
+__global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
 
 // ------------------------------------------------------------------------------------------
 // AdamW, all tensors in one launch
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adamw_kernel(const mmvae_adamw_item* __restrict__ items, float lr, float b1, float b2,
-                                                     float eps, float wd, float bc1, float rsqrt_bc2, int maximize) {
-    const mmvae_adamw_item it = items[blockIdx.y];
+struct AdamWBatch { mmvae_adamw_item items[64]; };      // passed BY VALUE (2.5 KiB of kernel arguments): no table upload,
+                                                        // so the launch is hipGraph-capturable even when gradients move
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, float lr, float b1, float b2,
+                                                     float eps, float wd, float bc1, float rsqrt_bc2, int maximize,
+                                                     const uint64_t* step_dev) {
+    const mmvae_adamw_item it = batch.items[blockIdx.y];
+    if (step_dev) {                                 // graph-capturable form: step count lives on the device
+        const float t = (float)(*step_dev + 1);
+        bc1 = 1.f - powf(b1, t);
+        rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
+    }
     const float step = lr / bc1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < it.n; i += (long)gridDim.x * blockDim.x) {
         float g = it.g[i];
@@ -350,7 +368,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 3; }
+extern "C" int mmvae_abi_version(void) { return 5; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -482,29 +500,43 @@ extern "C" int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const fl
     return 0;
 }
 
-extern "C" int mmvae_dropout_mask(uint8_t* mask, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream) {
-    if (!mask || n <= 0 || keep_prob < 0.f || keep_prob > 1.f || ((uintptr_t)mask & 15)) return MMVAE_ERR_ARG;
+extern "C" int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed,
+                           uint64_t offset, const uint64_t* offset_dev, void* stream) {
+    if ((n_mask > 0 && (!mask || ((uintptr_t)mask & 15))) || (n_eps > 0 && !eps) || n_mask < 0 || n_eps < 0 || n_mask + n_eps == 0 ||
+        keep_prob < 0.f || keep_prob > 1.f) return MMVAE_ERR_ARG;
     const double t = (double)keep_prob * 4294967296.0;
     const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, mask, n, thresh, seed, offset);
+    hipLaunchKernelGGL(noise_kernel, dim3(grid_for((n_mask + 15) / 16 + (n_eps + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       mask, n_mask, eps, n_eps, thresh, seed, offset, offset_dev);
     MM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int mmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
-    if (!out || n <= 0) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+extern "C" int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream) {
+    if (!counter_dev) return MMVAE_ERR_ARG;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, inc);
     MM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_dev, int32_t n_items, int64_t max_numel, float lr, float beta1,
+extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                                void* stream) {
-    if (!items_dev || n_items <= 0 || max_numel <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return MMVAE_ERR_ARG;
-    const int gx = grid_for(max_numel, 256 * 4, 256);
-    hipLaunchKernelGGL(adamw_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, items_dev, lr, beta1, beta2, eps,
-                       weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize);
-    MM_CHECK_LAUNCH();
+                                const uint64_t* step_dev, void* stream) {
+    if (!items_host || n_items <= 0 || (!step_dev && (bias_corr1 <= 0.f || bias_corr2 <= 0.f))) return MMVAE_ERR_ARG;
+    if (step_dev) { bias_corr1 = 1.f; bias_corr2 = 1.f; }
+    for (int base = 0; base < n_items; base += 64) {
+        AdamWBatch batch;
+        const int n = n_items - base < 64 ? n_items - base : 64;
+        int64_t max_numel = 1;
+        for (int i = 0; i < n; ++i) {
+            batch.items[i] = items_host[base + i];
+            if (!batch.items[i].p || !batch.items[i].g || !batch.items[i].m || !batch.items[i].v || batch.items[i].n <= 0) return MMVAE_ERR_ARG;
+            if (batch.items[i].n > max_numel) max_numel = batch.items[i].n;
+        }
+        const int gx = grid_for(max_numel, 256 * 4, 256);
+        hipLaunchKernelGGL(adamw_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, batch, lr, beta1, beta2, eps,
+                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev);
+        MM_CHECK_LAUNCH();
+    }
     return 0;
 }

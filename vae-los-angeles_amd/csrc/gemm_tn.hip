@@ -290,9 +290,11 @@ static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int&
     ntk = (K + TILE - 1) / TILE; ntiles = ntn * ntk;
     nsplit = nsplit_req;
     if (nsplit <= 0) {
-        // aim for ~2 workgroups per CU in total (every split adds one f32 atomic per output element),
-        // at least 4 m-tiles of work per workgroup
-        nsplit = (512 + ntiles - 1) / ntiles;
+        // ONE resident round: at most 2 workgroups per CU (512) in total and -- because split z runs on XCD z % 8 --
+        // a multiple of 8 splits so that every XCD gets the same share (a 520-block grid costs a whole extra round).
+        // Every split adds one f32 atomic per output element; keep at least 4 m-tiles of work per workgroup.
+        nsplit = 512 / ntiles;
+        if (nsplit >= 8) nsplit &= ~7;
         int max_split = (M + 4 * MT - 1) / (4 * MT);
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;

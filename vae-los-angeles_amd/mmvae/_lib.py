@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 5
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -114,9 +114,9 @@ _SIGNATURES = {
     "mmvae_loss_finalize": [vp, f32, f32, vp, vp],
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
-    "mmvae_dropout_mask": [vp, i64, f32, C.c_uint64, C.c_uint64, vp],
-    "mmvae_randn": [vp, i64, C.c_uint64, C.c_uint64, vp],
-    "mmvae_adamw_step": [vp, i32, i64, f32, f32, f32, f32, f32, f32, f32, i32, vp],
+    "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, vp],
+    "mmvae_counter_add": [vp, C.c_uint64, vp],
+    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp],
 }
 EXPORTED = ["mmvae_abi_version"] + sorted(_SIGNATURES)
 

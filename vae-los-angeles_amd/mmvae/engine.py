@@ -35,13 +35,14 @@ def default_precision():
 # noise
 # --------------------------------------------------------------------------------------------
 class NoiseSource:
-    """Dropout keep-masks and eps.  Default: Philox streams on the device keyed by
-    (torch.initial_seed() + rank, running offset).  `inject` replays explicit arrays in the
+    """Dropout keep-masks and eps.  Default: ONE Philox launch per forward (all masks of the pass in one uint8
+    buffer + eps), keyed by (torch.initial_seed() [+ rank], a DEVICE-resident running offset) -- the offset lives on
+    the device so that a captured hipGraph draws fresh noise on every replay.  `inject` replays explicit arrays in the
     order the reference consumes its RNG (EncoderA mask, EncoderB masks, eps): parity tests."""
 
     def __init__(self):
-        self.offset = 0
         self._injected = None
+        self._offsets = {}            # device -> int64[1] tensor (bit pattern of the uint64 Philox offset)
 
     def inject(self, masks, eps):
         self._injected = (list(masks), eps)
@@ -55,27 +56,38 @@ class NoiseSource:
             seed = (seed + 0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1)) & 0xFFFFFFFFFFFFFFFF
         return seed
 
-    def mask(self, B, N, device):
-        if self._injected is not None:
-            m = self._injected[0].pop(0)
-            if tuple(m.shape) != (B, N):
-                raise ValueError(f"injected mask shape {tuple(m.shape)} != {(B, N)}")
-            return m.to(device=device, dtype=torch.uint8).contiguous()
-        m = torch.empty(B, N, dtype=torch.uint8, device=device)
-        ops.dropout_mask(m, 1.0 - DROP_P, self._seed(), self.offset)
-        self.offset += (B * N + 3) // 4
-        return m
+    def offset_tensor(self, device):
+        t = self._offsets.get(device)
+        if t is None:
+            t = self._offsets[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        return t
 
-    def eps(self, B, Ld, device):
+    def draw(self, B, widths, Ld, device):
+        """-> ([uint8 (B,w) keep-mask for w in widths], eps fp32 (B,Ld) or None if Ld is None)."""
         if self._injected is not None:
-            e = self._injected[1]
-            if tuple(e.shape) != (B, Ld):
-                raise ValueError(f"injected eps shape {tuple(e.shape)} != {(B, Ld)}")
-            return e.to(device=device, dtype=torch.float32).contiguous()
-        e = torch.empty(B, Ld, dtype=torch.float32, device=device)
-        ops.randn(e, self._seed(), self.offset)
-        self.offset += (B * Ld + 3) // 4
-        return e
+            masks = []
+            for w in widths:
+                m = self._injected[0].pop(0)
+                if tuple(m.shape) != (B, w):
+                    raise ValueError(f"injected mask shape {tuple(m.shape)} != {(B, w)}")
+                masks.append(m.to(device=device, dtype=torch.uint8).contiguous())
+            eps = None
+            if Ld is not None:
+                eps = self._injected[1]
+                if tuple(eps.shape) != (B, Ld):
+                    raise ValueError(f"injected eps shape {tuple(eps.shape)} != {(B, Ld)}")
+                eps = eps.to(device=device, dtype=torch.float32).contiguous()
+            return masks, eps
+        segs, total = [], 0
+        for w in widths:
+            segs.append(total)
+            total = ceil_to(total + B * w, 16)
+        buf = torch.empty(total, dtype=torch.uint8, device=device) if total else None
+        eps = torch.empty(B, Ld, dtype=torch.float32, device=device) if Ld is not None else None
+        off = self.offset_tensor(device)
+        used = ops.noise(buf, eps, 1.0 - DROP_P, self._seed(), 0, off)
+        ops.counter_add(off, used)
+        return [buf[o:o + B * w].view(B, w) for o, w in zip(segs, widths)], eps
 
 
 GLOBAL_NOISE = NoiseSource()
@@ -132,7 +144,11 @@ class EncoderMLP:
         out += [self.fc_mu.weight, self.fc_logvar.weight, self.fc_mu.bias, self.fc_logvar.bias]
         return out
 
-    def forward(self, prec, x, train, noise):
+    def widths(self):
+        return [l.out_features for l in self.linears]
+
+    def forward(self, prec, x, train, masks):
+        """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval)."""
         B, dev = x.shape[0], x.device
         adt = act_dtype(prec)
         saved = []
@@ -148,7 +164,7 @@ class EncoderMLP:
                 ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
                                 bn.momentum if bn.momentum is not None else 0.1)
-                mask = noise.mask(B, N, dev)
+                mask = masks[len(saved)]
                 new_pro = (st.scale, st.shift, mask, 1.0 / (1.0 - DROP_P))
             else:
                 ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, tag=f"{self.name}.L{len(saved)}.fwd")
@@ -321,20 +337,22 @@ class VAEGraph:
         self._ensure_prepared(prec, dev)
         saved = {"prec": prec, "B": B, "train": train}
         heads_a = heads_b = table = None
+        Ld = self.latent
+        widths_a = self.enc_a.widths() if (train and xa is not None) else []
+        widths_b = self.enc_b.widths() if (train and xb is not None) else []
+        masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
-            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, self.noise)
+            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
-            heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, self.noise)
+            heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None)
         if site is not None:
             if site.dtype != torch.int64:
                 site = site.long()
             site = site.contiguous()
             table = self.enc_c.table()
             saved["site"] = site
-        Ld = self.latent
-        eps = self.noise.eps(B, Ld, dev)
         mu = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         logvar = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         z = torch.empty(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=dev)

@@ -275,7 +275,8 @@ class EncoderMLPFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         x = _check_input(x.reshape(x.shape[0], -1), "x", rt.block.in_dim)
         rt.ensure(prec, x.device)
-        heads, saved = rt.block.forward(prec, x, train, noise)
+        masks = noise.draw(x.shape[0], rt.block.widths(), None, x.device)[0] if train else None
+        heads, saved = rt.block.forward(prec, x, train, masks)
         ctx.rt, ctx.prec, ctx.saved = rt, prec, saved
         Ld = rt.block.latent
         return heads[:, :Ld], heads[:, Ld:]

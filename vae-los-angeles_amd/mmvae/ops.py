@@ -312,14 +312,28 @@ def scale_if_needed(x, scale):
     L.check(L.load().mmvae_scale_if_needed(x.data_ptr(), _dt(x), x.numel(), scale.data_ptr(), _stream()), "mmvae_scale_if_needed")
 
 
+def noise(mask, eps, keep_prob, seed, offset, offset_dev=None):
+    """Fill `mask` (uint8, any shape, contiguous; may be None) and `eps` (fp32; may be None) from the Philox stream
+    (seed, offset [+ *offset_dev]).  Returns the number of counter values consumed."""
+    n_mask = 0 if mask is None else mask.numel()
+    n_eps = 0 if eps is None else eps.numel()
+    L.check(L.load().mmvae_noise(_p(mask), n_mask, keep_prob, _p(eps), n_eps, seed, offset, _p(offset_dev), _stream()), "mmvae_noise")
+    return (n_mask + 15) // 16 * 4 + (n_eps + 3) // 4
+
+
 def dropout_mask(mask, keep_prob, seed, offset):
-    L.check(L.load().mmvae_dropout_mask(mask.data_ptr(), mask.numel(), keep_prob, seed, offset, _stream()), "mmvae_dropout_mask")
+    return noise(mask, None, keep_prob, seed, offset)
 
 
 def randn(out, seed, offset):
-    L.check(L.load().mmvae_randn(out.data_ptr(), out.numel(), seed, offset, _stream()), "mmvae_randn")
+    return noise(None, out, 1.0, seed, offset)
 
 
-def adamw_step(table, n_items, max_numel, lr, b1, b2, eps, wd, bc1, bc2, maximize=False):
-    L.check(L.load().mmvae_adamw_step(table.data_ptr(), n_items, max_numel, lr, b1, b2, eps, wd, bc1, bc2, int(maximize), _stream()),
-            "mmvae_adamw_step")
+def counter_add(counter, inc):
+    L.check(L.load().mmvae_counter_add(counter.data_ptr(), inc, _stream()), "mmvae_counter_add")
+
+
+def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=None):
+    """items: ctypes array of AdamWItem in host memory (device pointers inside)."""
+    L.check(L.load().mmvae_adamw_step(C.cast(items, C.c_void_p), len(items), lr, b1, b2, eps, wd, bc1, bc2, int(maximize),
+                                      _p(step_dev), _stream()), "mmvae_adamw_step")

@@ -1,10 +1,14 @@
 """FusedAdamW: torch.optim.AdamW semantics (the optimiser the reference's trainers construct,
 optimize_hyperparameters.py:93-97, train_dna2rna.py:185-189) with every parameter tensor updated
-by ONE HIP launch (mmvae_adamw_step) driven by a device-resident pointer table.
+by ONE HIP launch (mmvae_adamw_step); the (p, g, m, v) pointer records travel in the kernel arguments.
 
 State layout and hyper-parameter names follow torch.optim.AdamW (`exp_avg`, `exp_avg_sq`,
 `step`; `lr`, `betas`, `eps`, `weight_decay`, `maximize`) so `state_dict()` round-trips and LR
-schedulers such as ReduceLROnPlateau (train_dna2rna.py:190-195) work unchanged."""
+schedulers such as ReduceLROnPlateau (train_dna2rna.py:190-195) work unchanged.
+
+The step count used for the bias corrections lives ON THE DEVICE (one uint64 per step bucket,
+advanced by mmvae_counter_add after the launch), so `step()` is hipGraph-capturable: a replayed
+graph keeps counting.  `lr` is passed by value: re-capture when a scheduler changes it."""
 import ctypes as C
 
 import torch
@@ -19,22 +23,49 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
         self._tables = {}
+        self._step_dev = {}           # (group, host step at creation) -> int64[1] device counter
 
-    def _table(self, gi, entries):
+    def _table(self, key_id, entries):
+        """Host-side array of (p, g, m, v, n) records; the launch copies it into its kernel arguments."""
         key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()) for p, s in entries)
-        cached = self._tables.get(gi)
+        cached = self._tables.get(key_id)
         if cached is not None and cached[0] == key:
-            return cached[1], cached[2]
-        if len(self._tables) > 64:
-            self._tables.clear()
-        items = [L.AdamWItem(p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel())
-                 for p, s in entries]
-        arr = (L.AdamWItem * len(items))(*items)
-        dev = entries[0][0].device
-        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        max_numel = max(p.numel() for p, _ in entries)
-        self._tables[gi] = (key, table, max_numel)
-        return table, max_numel
+            return cached[1]
+        items = (L.AdamWItem * len(entries))(*[L.AdamWItem(p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(),
+                                                            s["exp_avg_sq"].data_ptr(), p.numel()) for p, s in entries])
+        self._tables[key_id] = (key, items)
+        return items
+
+    def _device_step(self, gi, bucket_step, device):
+        """Device counter holding (steps already applied) for the parameters of this bucket."""
+        k = (gi, str(device))
+        ent = self._step_dev.get(k)
+        if ent is None or ent[0] != bucket_step - 1:
+            t = torch.full((1,), bucket_step - 1, dtype=torch.int64, device=device)
+            ent = [bucket_step - 1, t]
+            self._step_dev[k] = ent
+        ent[0] = bucket_step
+        return ent[1]
+
+    def note_replayed_step(self):
+        """Bookkeeping after a hipGraph replay that contained step(): the device counters advanced, mirror it on the host."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] += 1
+        for ent in self._step_dev.values():
+            ent[0] += 1
+
+    def note_captured_step(self):
+        """A step() that ran under hipGraph CAPTURE only recorded launches: take its host-side counting back."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] -= 1
+        for ent in self._step_dev.values():
+            ent[0] -= 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -62,7 +93,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 buckets.setdefault(int(st["step"].item()), []).append((p, st))
             b1, b2 = group["betas"]
             for step_no, entries in buckets.items():
-                table, max_numel = self._table((gi, step_no if len(buckets) > 1 else 0), entries)
-                ops.adamw_step(table, len(entries), max_numel, float(group["lr"]), b1, b2, group["eps"],
-                               group["weight_decay"], 1.0 - b1 ** step_no, 1.0 - b2 ** step_no, group["maximize"])
+                single = len(buckets) == 1
+                items = self._table((gi, 0 if single else step_no), entries)
+                step_dev = self._device_step(gi if single else (gi, step_no), step_no, entries[0][0].device)
+                ops.adamw_step(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
+                               group["maximize"], step_dev=step_dev)
+                ops.counter_add(step_dev, 1)
         return loss

@@ -14,7 +14,7 @@ def reparameterize(mu, logvar):
     """z = mu + eps * exp(0.5*logvar), eps ~ N(0,1) sampled in train AND eval (vae.py:11-15).
     Stand-alone helper: eps comes from the device Philox stream; inside the models the same
     arithmetic is fused with the modality mean (mmvae_fuse_reparam_fwd)."""
-    eps = engine.GLOBAL_NOISE.eps(mu.shape[0], mu.shape[1], mu.device) if mu.is_cuda else torch.randn_like(mu)
+    eps = engine.GLOBAL_NOISE.draw(mu.shape[0], [], mu.shape[1], mu.device)[1] if mu.is_cuda else torch.randn_like(mu)
     return mu + eps * torch.exp(0.5 * logvar)
 
 
