@@ -108,6 +108,17 @@ def _check_input(x, name, cols):
     return x
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class BNState:
     """Per-layer BatchNorm vectors: rows of one [4][N] fp32 buffer (mean, rstd, scale, shift)."""
 
@@ -176,7 +187,7 @@ class EncoderMLP:
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
-    def backward(self, prec, saved, d_heads, grads):
+    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn):
         """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated)."""
         B, dev = d_heads.shape[0], d_heads.device
         adt = act_dtype(prec)
@@ -186,7 +197,7 @@ class EncoderMLP:
         Kl = self.pl_heads.K
         gw = grads[self.fc_mu.weight]            # fc_logvar.weight follows immediately in the arena
         gb = grads[self.fc_mu.bias]
-        ops.gemm_tn(prec, d_heads, y, _span(gw, L2 * Kl).view(L2, Kl), _span(gb, L2), L2, Kl, q_prologue=pro, tag=f"{self.name}.heads.dW")
+        tn(prec, d_heads, y, _span(gw, L2 * Kl).view(L2, Kl), _span(gb, L2), L2, Kl, q_prologue=pro, tag=f"{self.name}.heads.dW")
         # gradient entering the last hidden layer: dX GEMM of the heads (A = d_heads, W = heads^T)
         src, src_wt, src_n, src_k = d_heads, self.pl_heads.wt, Kl, L2
         for i in reversed(range(len(self.linears))):
@@ -201,7 +212,7 @@ class EncoderMLP:
             ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
             d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
             ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
-            ops.gemm_tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
+            tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
             src, src_wt, src_n, src_k = d, pl.wt, K, N
 
 
@@ -272,7 +283,7 @@ class DecoderMLP:
             h = out
         return h, acts
 
-    def backward(self, prec, acts, out, g_out, g_is_logit_grad, dz, accumulate_dz, grads):
+    def backward(self, prec, acts, out, g_out, g_is_logit_grad, dz, accumulate_dz, grads, tn=ops.gemm_tn):
         """g_out: gradient w.r.t. the decoder output ([B][>=N], fp32 or activation type).  For a
         sigmoid decoder it is w.r.t. the pre-sigmoid logits iff g_is_logit_grad."""
         B, dev = dz.shape[0], dz.device
@@ -284,7 +295,7 @@ class DecoderMLP:
             d = dl
         for j in reversed(range(len(self.pl))):
             pl, lin = self.pl[j], self.linears[j]
-            ops.gemm_tn(prec, d, acts[j], grads[lin.weight], grads[lin.bias], pl.N, pl.K, tag=f"{self.name}.L{j}.dW")
+            tn(prec, d, acts[j], grads[lin.weight], grads[lin.bias], pl.N, pl.K, tag=f"{self.name}.L{j}.dW")
             if j > 0:
                 d_prev = torch.empty(B, ceil_to(pl.K, 8), dtype=adt, device=dev)
                 ops.gemm_nt(prec, d, pl.wt, pl.K, pl.N, d_prev, epilogue=EPI_RELU_MASK, h=acts[j], tag=f"{self.name}.L{j}.dX")
@@ -310,6 +321,7 @@ class VAEGraph:
         self._prep_key = None
         self.noise = GLOBAL_NOISE
         self.grad_sync = None          # mmvae.parallel.GradAllReduce (early/final hooks) under data parallelism
+        self.overlap_dw = os.environ.get("MMVAE_OVERLAP_DW", "1") != "0"
 
     def param_list(self):
         out = []
@@ -386,13 +398,30 @@ class VAEGraph:
         Ld = self.latent
         flat, grads = self.alloc_grads(dev)
         dz = torch.zeros(B, Ld, dtype=torch.float32, device=dev)
+        # dW/db GEMMs have no consumer before the optimiser: they run on a second HIP stream beside the dX chain
+        # (under hipGraph capture this becomes a parallel branch of the graph)
+        tn, keep = ops.gemm_tn, []
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if self.overlap_dw else None
+        if side is not None:
+            def tn(prec_, p, q, *a, **kw):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                keep.extend((p, q))                       # operands stay alive until the join below
+                with torch.cuda.stream(side):
+                    ops.gemm_tn(prec_, p, q, *a, **kw)
         first = True
         for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):
             if g is None:
                 continue
-            dec.backward(prec, acts, out, g, is_logit, dz, not first, grads)
+            dec.backward(prec, acts, out, g, is_logit, dz, not first, grads, tn)
             first = False
         if self.grad_sync is not None:
+            if side is not None:                          # the decoder dW launches live on the side stream
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
             # decoder gradients (tail of the arena) are final: start reducing them under the encoder backward
             self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
         n_mod = saved["n_mod"]
@@ -403,11 +432,16 @@ class VAEGraph:
             d_table = torch.zeros(self.enc_c.embedding.weight.shape[0], 2 * Ld, dtype=torch.float32, device=dev)
         ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dz, saved["eps"], saved["logvar"], d_heads, d_table, site)
         if "enc_a" in saved:
-            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads)
+            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn)
         if "enc_b" in saved:
-            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads)
+            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn)
         if site is not None:
             self.enc_c.backward(d_table, grads)
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+            keep.clear()
         if self.grad_sync is not None:
             self.grad_sync.final(flat)
         return flat, grads
