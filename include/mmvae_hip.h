@@ -166,7 +166,7 @@ int mmvae_fuse_reparam_fwd(const mmvae_fuse_fwd_args* args, void* stream);
 typedef struct {
     int32_t B, L, n_mod;
     const float* g_mu; const float* g_lv;           /* may be NULL (treated as 0) */
-    const float* dz; int64_t lddz;
+    const float* dz; const float* dz2; const float* dz3; int64_t lddz;   /* dL/dz per decoder (dz2, dz3 may be NULL); summed */
     const float* eps; const float* logvar;
     float* d_heads; int64_t ld_heads;
     float* d_table; const int64_t* site; int32_t S;  /* may be NULL */

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mmvae_bn_bwd_final
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_table_fwd_kernel(int S, int E, int L, const float* emb, const float* w_mu,
                                                                const float* b_mu, const float* w_lv, const float* b_lv, float* table) {
-    for (int i = threadIdx.x; i < S * 2 * L; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * 2 * L; i += gridDim.x * blockDim.x) {
         const int s = i / (2 * L), j = i % (2 * L);
         const float* w = j < L ? w_mu + (long)j * E : w_lv + (long)(j - L) * E;
         float acc = j < L ? b_mu[j] : b_lv[j - L];
@@ -84,19 +84,20 @@ __global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int 
                                                                const float* w_lv, const float* dT, float* d_emb, float* d_w_mu,
                                                                float* d_b_mu, float* d_w_lv, float* d_b_lv) {
     const int L2 = 2 * L;
-    for (int i = threadIdx.x; i < S * E; i += blockDim.x) {           // dEmb = dT x Wcat
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t0; i < S * E; i += nt) {           // dEmb = dT x Wcat
         const int s = i / E, e = i % E;
         float acc = 0.f;
         for (int j = 0; j < L; ++j) acc += dT[s * L2 + j] * w_mu[(long)j * E + e] + dT[s * L2 + L + j] * w_lv[(long)j * E + e];
         d_emb[i] += acc;
     }
-    for (int i = threadIdx.x; i < L2 * E; i += blockDim.x) {          // dWcat = dT^T x emb
+    for (int i = t0; i < L2 * E; i += nt) {          // dWcat = dT^T x emb
         const int j = i / E, e = i % E;
         float acc = 0.f;
         for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * emb[(long)s * E + e];
         if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
     }
-    for (int j = threadIdx.x; j < L2; j += blockDim.x) {
+    for (int j = t0; j < L2; j += nt) {
         float acc = 0.f;
         for (int s = 0; s < S; ++s) acc += dT[s * L2 + j];
         if (j < L) d_b_mu[j] += acc; else d_b_lv[j - L] += acc;
@@ -132,7 +133,9 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
     const float inv_n = 1.f / (float)a.n_mod;
     for (long i = (long)b0 * a.L + threadIdx.x; i < (long)b1 * a.L; i += blockDim.x) {
         const int b = (int)(i / a.L), l = (int)(i % a.L);
-        const float dz = a.dz[(long)b * a.lddz + l];
+        float dz = a.dz[(long)b * a.lddz + l];
+        if (a.dz2) dz += a.dz2[(long)b * a.lddz + l];
+        if (a.dz3) dz += a.dz3[(long)b * a.lddz + l];
         const float gm = a.g_mu ? a.g_mu[i] : 0.f, gl = a.g_lv ? a.g_lv[i] : 0.f;
         float dmu = gm + dz;
         float dlv = gl + dz * a.eps[i] * expf(0.5f * a.logvar[i]) * 0.5f;
@@ -368,7 +371,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 5; }
+extern "C" int mmvae_abi_version(void) { return 6; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -404,7 +407,7 @@ extern "C" int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* a, void* 
 extern "C" int mmvae_embed_table_fwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* b_mu,
                                      const float* w_lv, const float* b_lv, float* table, void* stream) {
     if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !b_mu || !w_lv || !b_lv || !table) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(embed_table_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, E, L, emb, w_mu, b_mu, w_lv, b_lv, table);
+    hipLaunchKernelGGL(embed_table_fwd_kernel, dim3((S * 2 * L + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, E, L, emb, w_mu, b_mu, w_lv, b_lv, table);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -413,7 +416,8 @@ extern "C" int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const floa
                                      const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
                                      float* d_b_lv, void* stream) {
     if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !w_lv || !d_table || !d_emb || !d_w_mu || !d_b_mu || !d_w_lv || !d_b_lv) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(embed_table_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
+    const int work = S * E > 2 * L * E ? S * E : 2 * L * E;
+    hipLaunchKernelGGL(embed_table_bwd_kernel, dim3((work + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
     MM_CHECK_LAUNCH();
     return 0;
 }

@@ -68,6 +68,8 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     typename Src::Raw ra[4];
     Chunk<CT> rb[4];
     const int nk = (K + BK - 1) / BK;
+    EpiPrefetch pf;
+    if (!epi.accum()) nt_epilogue_prefetch<CT>(pf, epi, row0, col0, M, N, tid);
 
     auto fetch = [&](int kt) {
 #pragma unroll
@@ -109,7 +111,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         __syncthreads();
     }
 
-    nt_epilogue<CT>(smem, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+    nt_epilogue<CT>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
 }
 
 struct RingSrc { const void* a; long lda; };     // tag: plain bf16 A served by the LDS-ring kernel (gemm_ring.h)

@@ -82,9 +82,36 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     }
 };
 
+// Epilogue operand tiles (ReLU input / pre-BN output, keep mask) fetched into REGISTERS; issued before the main loop
+// so that their HBM latency is hidden under the contraction instead of being exposed between main loop and stores.
+struct EpiPrefetch { f32x4 h[8]; f32x4 m[4]; };
+
+template <typename CT, typename Epi>
+__device__ __forceinline__ void nt_epilogue_prefetch(EpiPrefetch& pf, const Epi& epi, int row0, int col0, int M, int N, int tid) {
+    typedef typename Epi::h_t HT;
+    if constexpr (sizeof(CT) == 2 && Epi::NEED >= 1 && sizeof(HT) == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + NTHREADS * i, r = c >> 4, ch = c & 15;
+            const int gr = row0 + r, gc = col0 + ch * 8;
+            pf.h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gr < M && gc < N) pf.h[i] = *(const f32x4*)(epi.H + (long)gr * epi.ldh + gc);     // rows padded to 8 elements
+        }
+        if (Epi::NEED >= 2 && epi.mask != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
+                const int gr = row0 + r, gc = col0 + ch * 16;
+                pf.m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gr < M && gc < N) pf.m[i] = *(const f32x4*)(epi.mask + (long)gr * epi.ldm + gc);   // N % 16 == 0 checked on the host
+            }
+        }
+    }
+}
+
 // smem: >= 48 KiB scratch (free to overwrite), red: 2 KiB.  wr/wc: wave row/column inside the tile.
 template <typename CT, typename Epi>
-__device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32x4 (&acc)[4][4], const Epi& epi,
+__device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32x4 (&acc)[4][4], const Epi& epi, const EpiPrefetch& pf,
                                             int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
 {
     typedef typename Epi::out_t OT;
@@ -97,23 +124,17 @@ __device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32
     if (CAN_STAGE && !epi.accum()) {
         unsigned char* sT = smem;                               // [128][128] of a 2-byte type, or [64][128] f32
         unsigned char* sM = smem + 2 * TILE * ROW_BYTES;        // [128][128] mask bytes
-        if (Epi::NEED >= 1) {                                   // stage the operand tile (ReLU input / pre-BN output)
+        if (Epi::NEED >= 1) {                                   // operand tiles: registers (prefetched) -> LDS
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = tid + NTHREADS * i, r = c >> 4, ch = c & 15;
-                const int gr = row0 + r, gc = col0 + ch * 8;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gr < M && gc < N) v = *(const f32x4*)(epi.H + (long)gr * epi.ldh + gc);     // rows padded to 8 elements
-                *(f32x4*)(sT + r * 256 + ch * 16) = v;
+                *(f32x4*)(sT + r * 256 + ch * 16) = pf.h[i];
             }
             if (Epi::NEED >= 2 && epi.mask != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
-                    const int gr = row0 + r, gc = col0 + ch * 16;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (gr < M && gc < N) v = *(const f32x4*)(epi.mask + (long)gr * epi.ldm + gc);   // N % 16 == 0 checked on the host
-                    *(f32x4*)(sM + r * 128 + ch * 16) = v;
+                    *(f32x4*)(sM + r * 128 + ch * 16) = pf.m[i];
                 }
             }
             __syncthreads();

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -74,7 +74,7 @@ class FuseFwdArgs(C.Structure):
 
 class FuseBwdArgs(C.Structure):
     _fields_ = [("B", i32), ("L", i32), ("n_mod", i32),
-                ("g_mu", vp), ("g_lv", vp), ("dz", vp), ("lddz", i64),
+                ("g_mu", vp), ("g_lv", vp), ("dz", vp), ("dz2", vp), ("dz3", vp), ("lddz", i64),
                 ("eps", vp), ("logvar", vp),
                 ("d_heads", vp), ("ld_heads", i64),
                 ("d_table", vp), ("site", vp), ("S", i32)]

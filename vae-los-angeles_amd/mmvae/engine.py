@@ -108,6 +108,16 @@ def _check_input(x, name, cols):
     return x
 
 
+def zeros_pack(device, specs):
+    """[(numel, dtype)] -> zero-filled tensors carved out of ONE allocation (one memset launch instead of one per tensor)."""
+    offs, total = [], 0
+    for n, dt in specs:
+        offs.append(total)
+        total += ceil_to(n * torch.empty(0, dtype=dt).element_size(), 16)
+    buf = torch.zeros(max(total, 16), dtype=torch.uint8, device=device)
+    return [buf[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for o, (n, dt) in zip(offs, specs)]
+
+
 _SIDE_STREAMS = {}
 
 
@@ -158,8 +168,9 @@ class EncoderMLP:
     def widths(self):
         return [l.out_features for l in self.linears]
 
-    def forward(self, prec, x, train, masks):
-        """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval)."""
+    def forward(self, prec, x, train, masks, stats_bufs=None):
+        """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval).
+        stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer."""
         B, dev = x.shape[0], x.device
         adt = act_dtype(prec)
         saved = []
@@ -170,7 +181,7 @@ class EncoderMLP:
             y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
             st = BNState(N, dev)
             if train:
-                stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+                stats = stats_bufs[len(saved)] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
                 ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd")
                 ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
@@ -187,7 +198,7 @@ class EncoderMLP:
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
-    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn):
+    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None):
         """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated)."""
         B, dev = d_heads.shape[0], d_heads.device
         adt = act_dtype(prec)
@@ -206,7 +217,7 @@ class EncoderMLP:
             N, K = pl.N, pl.K
             bnargs = (st.scale, st.shift, st.mean, st.rstd, pro[2], pro[3])
             # BatchNorm/ReLU/Dropout backward of layer i as two passes over the same contraction
-            stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+            stats = stats_bufs[i] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
             ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
             coef = torch.empty(3, N, dtype=torch.float32, device=dev)
             ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
@@ -353,12 +364,15 @@ class VAEGraph:
         widths_a = self.enc_a.widths() if (train and xa is not None) else []
         widths_b = self.enc_b.widths() if (train and xb is not None) else []
         masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
+        st_all = [t.view(2, -1) for t in zeros_pack(dev, [(2 * w, torch.float64) for w in widths_a + widths_b])] if train else []
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
-            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None)
+            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
+                                                         st_all[:len(widths_a)] if train else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
-            heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None)
+            heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
+                                                         st_all[len(widths_a):] if train else None)
         if site is not None:
             if site.dtype != torch.int64:
                 site = site.long()
@@ -380,15 +394,17 @@ class VAEGraph:
             saved["dec"].append((acts, o.detach()))
         return outs, mu, logvar, saved
 
-    def alloc_grads(self, device):
+    def alloc_grads(self, device, extra=()):
+        """Flat zeroed gradient arena + views per parameter (+ extra zeroed tensors from the same memset)."""
         params = self.param_list()
         total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        packed = zeros_pack(device, [(total, torch.float32)] + list(extra))
+        flat = packed[0]
         views, off = {}, 0
         for p in params:
             views[p] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
-        return flat, views
+        return flat, views, packed[1:]
 
     def backward(self, saved, g_outs, g_logit_flags, g_mu, g_lv):
         """g_outs[i]: gradient w.r.t. decoder i's output or None; g_mu/g_lv fp32 [B][L] or None.
@@ -396,8 +412,13 @@ class VAEGraph:
         prec, B = saved["prec"], saved["B"]
         dev = saved["eps"].device
         Ld = self.latent
-        flat, grads = self.alloc_grads(dev)
-        dz = torch.zeros(B, Ld, dtype=torch.float32, device=dev)
+        wa = self.enc_a.widths() if "enc_a" in saved else []
+        wb = self.enc_b.widths() if "enc_b" in saved else []
+        site = saved.get("site")
+        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * Ld if site is not None else 0
+        flat, grads, extra = self.alloc_grads(dev, [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)])
+        st_bwd = [t.view(2, -1) for t in extra[:-1]]
+        dzs = []                                       # one dL/dz per decoder; summed in mmvae_fuse_reparam_bwd
         # dW/db GEMMs have no consumer before the optimiser: they run on a second HIP stream beside the dX chain
         # (under hipGraph capture this becomes a parallel branch of the graph)
         tn, keep = ops.gemm_tn, []
@@ -415,8 +436,12 @@ class VAEGraph:
         for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):
             if g is None:
                 continue
-            dec.backward(prec, acts, out, g, is_logit, dz, not first, grads, tn)
+            dz = torch.empty(B, Ld, dtype=torch.float32, device=dev)
+            dec.backward(prec, acts, out, g, is_logit, dz, False, grads, tn)
+            dzs.append(dz)
             first = False
+        if not dzs:
+            dzs.append(torch.zeros(B, Ld, dtype=torch.float32, device=dev))
         if self.grad_sync is not None:
             if side is not None:                          # the decoder dW launches live on the side stream
                 ev = torch.cuda.Event()
@@ -426,15 +451,12 @@ class VAEGraph:
             self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
         n_mod = saved["n_mod"]
         d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
-        site = saved.get("site")
-        d_table = None
-        if site is not None:
-            d_table = torch.zeros(self.enc_c.embedding.weight.shape[0], 2 * Ld, dtype=torch.float32, device=dev)
-        ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dz, saved["eps"], saved["logvar"], d_heads, d_table, site)
+        d_table = extra[-1][:n_tab].view(-1, 2 * Ld) if site is not None else None
+        ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, saved["eps"], saved["logvar"], d_heads, d_table, site)
         if "enc_a" in saved:
-            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn)
+            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)])
         if "enc_b" in saved:
-            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn)
+            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):])
         if site is not None:
             self.enc_c.backward(d_table, grads)
         if side is not None:

@@ -327,7 +327,7 @@ class EmbedEncoderFn(torch.autograd.Function):
         d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
         d_table = torch.zeros(blk.embedding.weight.shape[0], 2 * Ld, dtype=torch.float32, device=dev)
         # dz = 0 and eps = 0: the kernel reduces to the scatter-add of (g_mu | g_lv) by class
-        ops.fuse_reparam_bwd(B, Ld, 1, g_mu, g_lv, zeros, zeros, zeros, d_heads, d_table, site)
+        ops.fuse_reparam_bwd(B, Ld, 1, g_mu, g_lv, [zeros], zeros, zeros, d_heads, d_table, site)
         grads = _alloc_block_grads(blk, dev)
         blk.backward(d_table, grads)
         out = [grads[p] for p in blk.params()]

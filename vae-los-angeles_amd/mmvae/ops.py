@@ -269,8 +269,10 @@ def fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z):
     L.check(L.load().mmvae_fuse_reparam_fwd(C.byref(a), _stream()), "mmvae_fuse_reparam_fwd")
 
 
-def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dz, eps, logvar, d_heads, d_table, site):
-    a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dz.data_ptr(), _ld(dz), eps.data_ptr(), logvar.data_ptr(),
+def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_table, site):
+    """dzs: 1..3 fp32 (B, Ld) tensors with one leading dimension (dL/dz of each decoder); they are summed."""
+    dzs = list(dzs) + [None] * (3 - len(dzs))
+    a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dzs[0].data_ptr(), _p(dzs[1]), _p(dzs[2]), _ld(dzs[0]), eps.data_ptr(), logvar.data_ptr(),
                       d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[0] if d_table is not None else 0)
     L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
 
