@@ -113,9 +113,12 @@ def zeros_pack(device, specs):
     offs, total = [], 0
     for n, dt in specs:
         offs.append(total)
-        total += ceil_to(n * torch.empty(0, dtype=dt).element_size(), 16)
+        total += ceil_to(n * _ITEMSIZE[dt], 16)
     buf = torch.zeros(max(total, 16), dtype=torch.uint8, device=device)
-    return [buf[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for o, (n, dt) in zip(offs, specs)]
+    return [buf[o:o + n * _ITEMSIZE[dt]].view(dt) for o, (n, dt) in zip(offs, specs)]
+
+
+_ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.uint8: 1, torch.int64: 8}
 
 
 _SIDE_STREAMS = {}
@@ -352,6 +355,10 @@ class VAEGraph:
 
     def forward(self, prec, xa, xb, site, train):
         """Returns (outs(list, fp32), mu, logvar, saved)."""
+        with ops.pinned_stream():
+            return self._forward(prec, xa, xb, site, train)
+
+    def _forward(self, prec, xa, xb, site, train):
         ref = xa if xa is not None else (xb if xb is not None else site)
         dev, B = ref.device, ref.shape[0]
         if not ref.is_cuda or any(p.device != dev for p in self.param_list()):
@@ -407,6 +414,10 @@ class VAEGraph:
         return flat, views, packed[1:]
 
     def backward(self, saved, g_outs, g_logit_flags, g_mu, g_lv):
+        with ops.pinned_stream():
+            return self._backward(saved, g_outs, g_logit_flags, g_mu, g_lv)
+
+    def _backward(self, saved, g_outs, g_logit_flags, g_mu, g_lv):
         """g_outs[i]: gradient w.r.t. decoder i's output or None; g_mu/g_lv fp32 [B][L] or None.
         Returns (flat_arena, {param: grad view})."""
         prec, B = saved["prec"], saved["B"]
@@ -430,7 +441,7 @@ class VAEGraph:
                 ev.record(main)
                 side.wait_event(ev)
                 keep.extend((p, q))                       # operands stay alive until the join below
-                with torch.cuda.stream(side):
+                with ops.pinned_stream(side):
                     ops.gemm_tn(prec_, p, q, *a, **kw)
         first = True
         for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):

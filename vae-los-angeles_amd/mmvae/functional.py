@@ -160,6 +160,11 @@ def _tag_of(t):
 
 
 def fused_loss(terms, beta, gamma, class_weights=None):
+    with ops.pinned_stream():
+        return _fused_loss(terms, beta, gamma, class_weights)
+
+
+def _fused_loss(terms, beta, gamma, class_weights=None):
     """terms: dict with optional entries
          'a': (recon_a, a)  sum-MSE           'b': (recon_b, b)  sum-BCE (clamped logs)
          'c': (logits, site) weighted sum-CE  'kl': (mu, logvar)

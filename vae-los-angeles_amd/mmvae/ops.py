@@ -65,8 +65,29 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_STREAM_OVERRIDE = None     # raw hipStream_t handle pinned by engine code for a span of launches (torch.cuda.current_stream()
+                            # costs ~10 us per query, more than building the argument struct)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+    """Context manager: resolve the current stream ONCE and use its handle for every launch inside."""
+
+    def __init__(self, stream=None):
+        self.handle = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+
+    def __enter__(self):
+        global _STREAM_OVERRIDE
+        self.prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = self.prev
+        return False
 
 
 def _mat(t, name):

@@ -24,6 +24,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
         self._tables = {}
         self._step_dev = {}           # (group, host step at creation) -> int64[1] device counter
+        self._fast = {}               # group -> [params, grad ptrs, records, pending host steps, device counter]
 
     def _table(self, key_id, entries):
         """Host-side array of (p, g, m, v, n) records; the launch copies it into its kernel arguments."""
@@ -49,6 +50,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def note_replayed_step(self):
         """Bookkeeping after a hipGraph replay that contained step(): the device counters advanced, mirror it on the host."""
+        self._sync_fast_steps()
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state.get(p)
@@ -59,6 +61,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def note_captured_step(self):
         """A step() that ran under hipGraph CAPTURE only recorded launches: take its host-side counting back."""
+        self._sync_fast_steps()
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state.get(p)
@@ -75,6 +78,21 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
             buckets = {}            # step number -> [(param, state)]; normally a single bucket
+            fast = self._fast.get(gi)
+            if fast is not None and all(p.grad is not None and p.grad.data_ptr() == g for p, g in zip(fast[0], fast[1])):
+                # steady state: same parameters, gradients at the same addresses as last step -> reuse records,
+                # one shared host step counter (the per-parameter `step` tensors are refreshed in state_dict())
+                fast[3] += 1
+                b1, b2 = group["betas"]
+                with ops.pinned_stream():
+                    ops.adamw_step(fast[2], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
+                                   group["maximize"], step_dev=fast[4])
+                    ops.counter_add(fast[4], 1)
+                for ent in self._step_dev.values():
+                    if ent[1] is fast[4]:
+                        ent[0] += 1
+                continue
+            self._sync_fast_steps(gi)
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -99,4 +117,23 @@ class FusedAdamW(torch.optim.Optimizer):
                 ops.adamw_step(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
                                group["maximize"], step_dev=step_dev)
                 ops.counter_add(step_dev, 1)
+                if single:
+                    ps = [p for p, _ in entries]
+                    self._fast[gi] = [ps, [p.grad.data_ptr() for p in ps], items, 0, step_dev]
         return loss
+
+    def _sync_fast_steps(self, gi=None):
+        """Fold the steps taken on the fast path back into the per-parameter `step` tensors."""
+        for g, fast in list(self._fast.items()):
+            if gi is not None and g != gi:
+                continue
+            if fast[3]:
+                for p in fast[0]:
+                    self.state[p]["step"] += fast[3]
+                fast[3] = 0
+            if gi is not None:
+                del self._fast[g]
+
+    def state_dict(self):
+        self._sync_fast_steps()
+        return super().state_dict()
