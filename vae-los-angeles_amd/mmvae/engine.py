@@ -355,6 +355,10 @@ class VAEGraph:
 
     def forward(self, prec, xa, xb, site, train):
         """Returns (outs(list, fp32), mu, logvar, saved)."""
+        ref = xa if xa is not None else (xb if xb is not None else site)
+        if not ref.is_cuda:
+            raise RuntimeError(f"the MI355X path needs inputs and parameters on one CUDA/HIP device (input on {ref.device}); "
+                               "there is no CPU fallback")
         with ops.pinned_stream():
             return self._forward(prec, xa, xb, site, train)
 

@@ -160,6 +160,8 @@ def _tag_of(t):
 
 
 def fused_loss(terms, beta, gamma, class_weights=None):
+    if not next(v[0] for v in terms.values() if v is not None).is_cuda:
+        raise RuntimeError("the MI355X loss kernel needs CUDA/HIP tensors; there is no CPU fallback")
     with ops.pinned_stream():
         return _fused_loss(terms, beta, gamma, class_weights)
 
