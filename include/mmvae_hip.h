@@ -94,8 +94,8 @@ int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * dW[N,K] += P[M,N]^T x Q[M,K] ;  db[N] += column sums of P      (gemm_tn.hip)
  *   P = gradient w.r.t. the layer output, Q = the layer input (optionally through the same
- *   BN+ReLU+Dropout prologue as above).  dW/db are fp32 and ACCUMULATED with atomics: zero them
- *   first.  nsplit <= 0 lets the library choose the batch split.
+ *   BN+ReLU+Dropout prologue as above).  dW/db are fp32 and ACCUMULATED (dW through the slab workspace or f32
+ *   atomics, db with atomics): zero them first.  nsplit <= 0 lets the library choose the batch split (<= 64).
  * Replaces: the dW mm and db sum of each Linear backward (optimize_hyperparameters.py:112).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -106,6 +106,8 @@ typedef struct {
     const float* pro_scale; const float* pro_shift; const uint8_t* pro_mask; int64_t ld_pro_mask; float pro_inv_keep;
     float* dw; int64_t lddw; float* db;
     int32_t nsplit;
+    float* slab; int64_t slab_elems;   /* optional workspace: when it holds nsplit*N*K floats the splits store partial tiles there
+                                          and a second launch sums them in fixed order (deterministic dW, no atomics); else atomics */
 } mmvae_gemm_tn_args;
 int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x4 tn_frag(const unsigned char* tile, int colbase,
 template <typename CT, typename PSrc, typename QSrc>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
-                    int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, int use_atomic)
+                    int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
 {
     typedef TnGeom<CT> G;
     constexpr int EPC = Mma<CT>::EPC;
@@ -159,8 +159,10 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             for (int b = 0; b < 4; ++b) {
                 const int k = k0 + wc * 64 + b * 16 + (lane & 15);
                 if (k < K) {
-                    float* q = dW + (long)n * ldw + k;
-                    if (use_atomic) unsafeAtomicAdd(q, acc[a][b][j]); else *q += acc[a][b][j];
+                    // slab form: this split's partial tile is stored plainly into slab[zz] and summed by tn_reduce_kernel
+                    // (deterministic, no memory-side atomics); otherwise f32 atomics straight into dW
+                    if (slab) slab[((long)zz * N + n) * K + k] = acc[a][b][j];
+                    else unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
                 }
             }
         }
@@ -184,7 +186,7 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
 __global__ __launch_bounds__(NTHREADS, 1)
 void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes, const bf16* __restrict__ Q, long ldq, unsigned q_bytes,
                          float* __restrict__ dW, long ldw, float* __restrict__ db,
-                         int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split)
+                         int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
 {
     typedef TnGeom<bf16> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -271,7 +273,10 @@ void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes,
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int k = k0 + wc * 64 + b * 16 + (lane & 15);
-                if (k < K) unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
+                if (k < K) {
+                    if (slab) slab[((long)zz * N + n) * K + k] = acc[a][b][j];
+                    else unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
+                }
             }
         }
     if (do_bias) {
@@ -283,6 +288,26 @@ void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes,
             if (lane < 16 && n < N) unsafeAtomicAdd(db + n, v);
         }
     }
+}
+
+// dW[n][k] += sum_z slab[z][n][k]   (fixed summation order -> bitwise reproducible weight gradients)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, int nsplit, long nk, float* __restrict__ dW,
+                                                        long ldw, int K) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slab[z * nk + i];
+        const long n = i / K, k = i - n * K;
+        dW[n * ldw + k] += s;
+    }
+}
+
+static int tn_reduce(const mmvae_gemm_tn_args* a, int nsplit, hipStream_t st) {
+    const long nk = (long)a->N * a->K;
+    int grid = (int)((nk + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid), dim3(256), 0, st, a->slab, nsplit, nk, a->dw, a->lddw, a->K);
+    MM_CHECK_LAUNCH();
+    return 0;
 }
 
 static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int& ntiles, int& nsplit, int& rps) {
@@ -314,11 +339,12 @@ static int launch_tn_ring(const mmvae_gemm_tn_args* a, hipStream_t st) {
     int ntk, ntiles, nsplit, rps;
     tn_split(a->M, a->N, a->K, 64, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
+    float* slab = (a->slab && nsplit > 1 && (long)nsplit * a->N * a->K <= a->slab_elems) ? a->slab : nullptr;
     hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(grid), dim3(NTHREADS), RING_LDS, st,
                        (const bf16*)a->p, a->ldp, (unsigned)((long)a->M * a->ldp * 2), (const bf16*)a->q, a->ldq,
-                       (unsigned)((long)a->M * a->ldq * 2), a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps);
+                       (unsigned)((long)a->M * a->ldq * 2), a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
     MM_CHECK_LAUNCH();
-    return 0;
+    return slab ? tn_reduce(a, nsplit, st) : 0;
 }
 
 template <typename CT, typename PSrc, typename QSrc>
@@ -327,10 +353,11 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     int ntk, ntiles, nsplit, rps;
     tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
+    float* slab = (a->slab && nsplit > 1 && (long)nsplit * a->N * a->K <= a->slab_elems) ? a->slab : nullptr;
     hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), 0, st, ps, qs,
-                       a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, 1);
+                       a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
     MM_CHECK_LAUNCH();
-    return 0;
+    return slab ? tn_reduce(a, nsplit, st) : 0;
 }
 
 template <typename CT, typename PSrc>

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -49,7 +49,7 @@ class GemmTnArgs(C.Structure):
                 ("q_prologue", i32),
                 ("pro_scale", vp), ("pro_shift", vp), ("pro_mask", vp), ("ld_pro_mask", i64), ("pro_inv_keep", f32),
                 ("dw", vp), ("lddw", i64), ("db", vp),
-                ("nsplit", i32)]
+                ("nsplit", i32), ("slab", vp), ("slab_elems", i64)]
 
 
 class BnFinalizeArgs(C.Structure):

@@ -436,7 +436,14 @@ class VAEGraph:
         dzs = []                                       # one dL/dz per decoder; summed in mmvae_fuse_reparam_bwd
         # dW/db GEMMs have no consumer before the optimiser: they run on a second HIP stream beside the dX chain
         # (under hipGraph capture this becomes a parallel branch of the graph)
-        tn, keep = ops.gemm_tn, []
+        # slab workspace for the split-batch dW GEMMs (<= 64 splits of the largest weight matrix); launches that use it
+        # run one after another on one stream, so a single buffer serves them all
+        big = max(p.numel() for p in self.param_list())
+        slab = torch.empty(64 * big, dtype=torch.float32, device=dev)
+        keep = []
+
+        def tn(prec_, p, q, *a, **kw):
+            ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if self.overlap_dw else None
         if side is not None:
@@ -446,7 +453,7 @@ class VAEGraph:
                 side.wait_event(ev)
                 keep.extend((p, q))                       # operands stay alive until the join below
                 with ops.pinned_stream(side):
-                    ops.gemm_tn(prec_, p, q, *a, **kw)
+                    ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         first = True
         for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):
             if g is None:

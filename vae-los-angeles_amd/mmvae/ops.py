@@ -216,7 +216,7 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
     return out
 
 
-def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, tag=None):
+def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, slab=None, tag=None):
     """dw[N,K] += p[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(p).  dw/db fp32, pre-zeroed."""
     _mat(p, "p"); _mat(q, "q")
     g = L.GemmTnArgs()
@@ -232,6 +232,8 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, tag=None):
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     g.dw, g.lddw, g.db = dw.data_ptr(), K, _p(db)
     g.nsplit = nsplit
+    if slab is not None:
+        g.slab, g.slab_elems = slab.data_ptr(), slab.numel()
     t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_tn(C.byref(g), _stream()), "mmvae_gemm_tn")
     if t0 is not None:
