@@ -145,3 +145,31 @@ def test_graphed_train_step_matches_eager():
         d = (p1 - p2).abs()          # Adam amplifies atomics-order noise on near-zero gradients to +-lr per step
         assert float(d.max()) <= 10 * 1e-3 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
     assert int(o2.state[next(iter(m2.parameters()))]["step"].item()) == n_warm + 1 + n_run
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_scaled_omics_widths(prec):
+    """BASELINE configs[4] widths (RNA=20000, DNA=27000, latent=128) at a small batch: one step against the oracle
+    (generic K/N tail handling, 211-tile-wide dW grids, heads with N=256)."""
+    A, D, S, L, E, B = 20000, 27000, 24, 128, 32, 192
+    P, Bf = O.make_params(5, A, D, S, L, E)
+    a, b, site = O.make_batch(6, B, A, D, S)
+    masks, eps = O.make_noise(7, B, L)
+    P64, Bf64 = f64(P), f64(Bf)
+    oa, ob, oc, mu, lv, cache = O.vae_forward(P64, Bf64, a.astype(np.float64), b.astype(np.float64), site, masks, eps.astype(np.float64), True)
+    tot, rec, cls, kld, g = O.vae_loss(oa, a.astype(np.float64), ob, b.astype(np.float64), oc, site, mu, lv)
+    G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b"], g["recon_c"], g["mu"], g["logvar"])
+    model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), P, Bf).to(DEV).set_precision(prec).train()
+    ta, tb, ts = (torch.from_numpy(x).to(DEV) for x in (a, b, site))
+    engine.GLOBAL_NOISE.inject(masks_list(masks), torch.from_numpy(eps))
+    ra, rb, rc, m_, l_ = model(a=ta, b=tb, site=ts)
+    loss, r_, c_, k_ = vae_loss(ra, ta, rb, tb, rc, ts, m_, l_)
+    engine.GLOBAL_NOISE.clear()
+    loss.backward()
+    tol_out, tol_loss, tol_fro = (1e-4, 2e-5, 2e-3) if prec == "fp32" else (3e-2, 3e-3, 0.25)
+    for got, want in ((ra, oa), (rb, ob), (m_, mu), (l_, lv)):
+        assert float(np.abs(got.detach().cpu().numpy() - want).max() / np.abs(want).max()) <= tol_out
+    assert abs(loss.item() - tot) <= tol_loss * abs(tot)
+    for k in ("encoder_b.fc.0.weight", "decoder_b.fc.4.weight", "encoder_a.fc_mu.weight", "decoder_a.fc.0.weight"):
+        gv = dict(model.named_parameters())[k].grad.cpu().numpy()
+        assert float(np.linalg.norm(gv - G[k]) / np.linalg.norm(G[k])) <= tol_fro, k

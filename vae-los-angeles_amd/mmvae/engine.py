@@ -439,7 +439,7 @@ class VAEGraph:
         # slab workspace for the split-batch dW GEMMs (<= 64 splits of the largest weight matrix); launches that use it
         # run one after another on one stream, so a single buffer serves them all
         big = max(p.numel() for p in self.param_list())
-        slab = torch.empty(64 * big, dtype=torch.float32, device=dev)
+        slab = torch.empty(min(64 * big, 1 << 25), dtype=torch.float32, device=dev)     # <= 128 MiB; too small -> that GEMM uses atomics
         keep = []
 
         def tn(prec_, p, q, *a, **kw):
