@@ -86,7 +86,7 @@ typedef struct {
     const void* h; int64_t ldh;
     const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;
     const uint8_t* epi_mask; int64_t ld_epi_mask; float epi_inv_keep;
-    const float* bn_coef; int32_t bn_phase;       /* MMVAE_EPI_BN_BWD: phase 0 = statistics, 1 = apply */
+    const float* bn_coef; int32_t bn_phase;       /* MMVAE_EPI_BN_BWD: 0 = statistics, 1 = apply (recompute), 2 = statistics + store d */
     double* stat1; double* stat2;                 /* optional [N] f64 accumulators (atomic adds; zero them first) */
 } mmvae_gemm_nt_args;
 int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
@@ -135,6 +135,10 @@ typedef struct {
     float* dgamma; float* dbeta; float* coef;           /* coef: [3][N] */
 } mmvae_bn_bwd_finalize_args;
 int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* args, void* stream);
+/* d <- coef0 * (d - coef1 - xhat*coef2), xhat = (y-mean)*rstd, in place on the activation-typed buffer d written by
+ * MMVAE_EPI_BN_BWD bn_phase 2 (the one-contraction form of BatchNorm backward). */
+int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                       const float* mean, const float* rstd, const float* coef, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EncoderC (encoders.py:57-61): Embedding + two heads == a per-class table

@@ -66,6 +66,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mmvae_bn_bwd_final
     }
 }
 
+template <typename GT, int V> __device__ __forceinline__ void store_vec(GT* p, const float* v);
+
+// dy = c0 * (d - c1 - xhat * c2), xhat = (y - mean) * rstd, in place on d; V elements per thread, N % V == 0
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int N, T* d, long ldd, const T* y, long ldy,
+                                                            const float* mean, const float* rstd, const float* coef) {
+    const unsigned vpr = N / V, total = (unsigned)M * vpr;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / vpr, c = (i - r * vpr) * V;
+        float dv[V], yv[V], o[V];
+        VLoad<T, V>::ld(d + (long)r * ldd + c, dv);
+        VLoad<T, V>::ld(y + (long)r * ldy + c, yv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (yv[e] - mean[c + e]) * rstd[c + e];
+            o[e] = coef[c + e] * (dv[e] - coef[N + c + e] - xh * coef[2 * N + c + e]);
+        }
+        store_vec<T, V>(d + (long)r * ldd + c, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // EncoderC table
 // ------------------------------------------------------------------------------------------
@@ -371,7 +392,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 7; }
+extern "C" int mmvae_abi_version(void) { return 8; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -400,6 +421,21 @@ extern "C" int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* a, void* 
     if (!a || !a->sum_d || !a->sum_dx || !a->gamma || !a->rstd || !a->dgamma || !a->dbeta || !a->coef) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0) return MMVAE_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                                  const float* mean, const float* rstd, const float* coef, void* stream) {
+    if (M <= 0 || N <= 0 || !d || !y || !mean || !rstd || !coef || (long)M * N >= (1L << 32)) return MMVAE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMVAE_BF16) {
+        if (N % 8 || ldd % 8 || ldy % 8 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 8>), dim3(grid_for((long)M * N / 8, 256, 4096)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef);
+    } else {
+        if (N % 4 || ldd % 4 || ldy % 4 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(grid_for((long)M * N / 4, 256, 4096)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef);
+    }
     MM_CHECK_LAUNCH();
     return 0;
 }

@@ -164,7 +164,10 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
     }
     case MMVAE_EPI_BN_BWD: {
         if (a->h == nullptr || !a->bn_scale || !a->bn_shift || !a->bn_mean || !a->bn_rstd) return MMVAE_ERR_ARG;
-        if (a->bn_phase == 0 ? (!a->stat1 || !a->stat2) : (!a->bn_coef || !a->c)) return MMVAE_ERR_ARG;
+        if (a->bn_phase < 0 || a->bn_phase > 2) return MMVAE_ERR_ARG;
+        if (a->bn_phase != 1 && (!a->stat1 || !a->stat2)) return MMVAE_ERR_ARG;
+        if (a->bn_phase == 1 && !a->bn_coef) return MMVAE_ERR_ARG;
+        if (a->bn_phase != 0 && !a->c) return MMVAE_ERR_ARG;
         if (a->bn_phase && (a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
         if (sizeof(LP) == 2) {
             if (a->ldh % 8 || ((uintptr_t)a->h & 15)) return MMVAE_ERR_ARG;
@@ -173,7 +176,7 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
         }
         EpiBnBwd<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->epi_mask, a->ld_epi_mask,
                            a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd, a->epi_inv_keep, a->bn_coef, a->bn_phase,
-                           a->bn_phase ? nullptr : a->stat1, a->bn_phase ? nullptr : a->stat2};
+                           a->bn_phase == 1 ? nullptr : a->stat1, a->bn_phase == 1 ? nullptr : a->stat2};
         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
     }
     }

@@ -55,6 +55,7 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     //   phase 0: nothing stored; stats = (sum d, sum d*xhat)  -> mmvae_bn_bwd_finalize -> coef
     //   phase 1: C = coef0 * (d - coef1 - xhat*coef2)          (d recomputed from the f32 accumulators, so
     //            the cancellation happens before the single rounding to the activation type)
+    //   phase 2: C = d and the same statistics as phase 0 (one contraction; mmvae_bn_bwd_apply finishes in place)
     static constexpr bool STATS = true;
     static constexpr int NEED = 2;
     typedef OT out_t; typedef YT h_t;
@@ -69,7 +70,7 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
         Col k{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (c < N) {
             k.sc = scale[c]; k.sh = shift[c]; k.mu = mean[c]; k.rs = rstd[c];
-            if (phase) { k.c0 = coef[c]; k.c1 = coef[N + c]; k.c2 = coef[2 * N + c]; }
+            if (phase == 1) { k.c0 = coef[c]; k.c1 = coef[N + c]; k.c2 = coef[2 * N + c]; }
         }
         return k;
     }
@@ -77,7 +78,7 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
         const float keep = mask ? (mb ? inv_keep : 0.f) : 1.f;
         const float d = (y * cc.sc + cc.sh > 0.f) ? v * keep : 0.f;
         const float xh = (y - cc.mu) * cc.rs;
-        if (phase == 0) { if (count) { s1 += d; s2 += d * xh; } return 0.f; }
+        if (phase != 1) { if (count) { s1 += d; s2 += d * xh; } return d; }      // 0: statistics only; 2: statistics + store d
         return cc.c0 * (d - cc.c1 - xh * cc.c2);
     }
 };

@@ -295,10 +295,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
                                                         long ldw, int K) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += slab[z * nk + i];
+#pragma unroll 8
+        for (int z = 0; z < nsplit; ++z) s += slab[z * nk + i];       // independent loads: 8 in flight per thread
         const long n = i / K, k = i - n * K;
         dW[n * ldw + k] += s;
     }
+}
+
+// Slabs pay when a LARGE weight matrix is split a few dozen ways (tens of MB of atomics otherwise); a small matrix split
+// hundreds of ways (heads, 40 x 256) would turn the reduce into a latency-bound crawl: those keep the f32 atomics.
+static bool tn_use_slab(const mmvae_gemm_tn_args* a, int nsplit) {
+    const long nk = (long)a->N * a->K;
+    return a->slab && nsplit > 1 && nsplit <= 64 && nk >= 32768 && nsplit * nk <= a->slab_elems;
 }
 
 static int tn_reduce(const mmvae_gemm_tn_args* a, int nsplit, hipStream_t st) {
@@ -339,7 +347,7 @@ static int launch_tn_ring(const mmvae_gemm_tn_args* a, hipStream_t st) {
     int ntk, ntiles, nsplit, rps;
     tn_split(a->M, a->N, a->K, 64, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
-    float* slab = (a->slab && nsplit > 1 && (long)nsplit * a->N * a->K <= a->slab_elems) ? a->slab : nullptr;
+    float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
     hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(grid), dim3(NTHREADS), RING_LDS, st,
                        (const bf16*)a->p, a->ldp, (unsigned)((long)a->M * a->ldp * 2), (const bf16*)a->q, a->ldq,
                        (unsigned)((long)a->M * a->ldq * 2), a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
@@ -353,7 +361,7 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     int ntk, ntiles, nsplit, rps;
     tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
-    float* slab = (a->slab && nsplit > 1 && (long)nsplit * a->N * a->K <= a->slab_elems) ? a->slab : nullptr;
+    float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
     hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), 0, st, ps, qs,
                        a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
     MM_CHECK_LAUNCH();

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -106,6 +106,7 @@ _SIGNATURES = {
     "mmvae_bn_finalize": [C.POINTER(BnFinalizeArgs), vp],
     "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],
+    "mmvae_bn_bwd_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp],
     "mmvae_embed_table_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "mmvae_embed_table_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mmvae_fuse_reparam_fwd": [C.POINTER(FuseFwdArgs), vp],

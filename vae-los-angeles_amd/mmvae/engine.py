@@ -19,6 +19,7 @@ from .ops import (PREC_BF16, PREC_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, EPI_RELU
 
 _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
+_BN_BWD_RECOMPUTE = os.environ.get("MMVAE_BN_BWD_RECOMPUTE", "0") == "1"
 
 
 def set_default_precision(name):
@@ -132,6 +133,13 @@ def _side_stream(device):
     return st
 
 
+def _fork(src, dst):
+    """dst waits for everything enqueued on src so far (event record + wait)."""
+    ev = torch.cuda.Event()
+    ev.record(src)
+    dst.wait_event(ev)
+
+
 class BNState:
     """Per-layer BatchNorm vectors: rows of one [4][N] fp32 buffer (mean, rstd, scale, shift)."""
 
@@ -219,13 +227,20 @@ class EncoderMLP:
             h_in, pro_in, y, st, pro = saved[i]
             N, K = pl.N, pl.K
             bnargs = (st.scale, st.shift, st.mean, st.rstd, pro[2], pro[3])
-            # BatchNorm/ReLU/Dropout backward of layer i as two passes over the same contraction
+            # BatchNorm/ReLU/Dropout backward of layer i: ONE contraction that stores d = dX * keep * relu' and accumulates
+            # (sum d, sum d*xhat); then the BN correction in place (mmvae_bn_bwd_apply).  The recompute form (two contractions,
+            # nothing stored in between) stays available: MMVAE_BN_BWD_RECOMPUTE=1.
             stats = stats_bufs[i] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
-            ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
             coef = torch.empty(3, N, dtype=torch.float32, device=dev)
-            ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
             d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
-            ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
+            if _BN_BWD_RECOMPUTE:
+                ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+                ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
+            else:
+                ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+                ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
             tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
             src, src_wt, src_n, src_k = d, pl.wt, K, N
 
@@ -376,10 +391,17 @@ class VAEGraph:
         widths_b = self.enc_b.widths() if (train and xb is not None) else []
         masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
         st_all = [t.view(2, -1) for t in zeros_pack(dev, [(2 * w, torch.float64) for w in widths_a + widths_b])] if train else []
+        # independent chains run on two HIP streams (parallel branches under hipGraph capture): EncoderA beside EncoderB,
+        # the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if (self.overlap_dw and xa is not None and xb is not None) else None
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
-            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
-                                                         st_all[:len(widths_a)] if train else None)
+            if side is not None:
+                _fork(main, side)
+            with ops.pinned_stream(side if side is not None else main):
+                heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
+                                                             st_all[:len(widths_a)] if train else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
             heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
@@ -390,6 +412,8 @@ class VAEGraph:
             site = site.contiguous()
             table = self.enc_c.table()
             saved["site"] = site
+        if side is not None:
+            _fork(side, main)                          # join: the fusion kernel needs EncoderA's heads
         mu = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         logvar = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         z = torch.empty(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=dev)
@@ -398,11 +422,18 @@ class VAEGraph:
         # autograd node (tensor -> grad_fn -> ctx -> saved -> tensor would be a cycle only the cyclic GC frees,
         # i.e. every step's activations would pile up in HBM until it runs)
         saved.update(eps=eps, logvar=logvar.detach(), n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
-        outs, saved["dec"] = [], []
-        for dec in self.decoders:
-            o, acts = dec.forward(prec, z)
-            outs.append(o)
-            saved["dec"].append((acts, o.detach()))
+        outs, saved["dec"] = [None] * len(self.decoders), [None] * len(self.decoders)
+        order = sorted(range(len(self.decoders)), key=lambda i: -sum(l.weight.numel() for l in self.decoders[i].linears))
+        dside = _side_stream(dev) if (self.overlap_dw and len(order) > 1) else None
+        if dside is not None:
+            _fork(main, dside)
+        for rank_, i in enumerate(order):               # largest decoder on the main stream, the others beside it
+            with ops.pinned_stream(dside if (dside is not None and rank_ > 0) else main):
+                o, acts = self.decoders[i].forward(prec, z)
+            outs[i] = o
+            saved["dec"][i] = (acts, o.detach())
+        if dside is not None:
+            _fork(dside, main)
         return outs, mu, logvar, saved
 
     def alloc_grads(self, device, extra=()):

@@ -175,7 +175,7 @@ class WeightPrep:
 # GEMMs
 # --------------------------------------------------------------------------------------------
 def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
-            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, stats=None, tag=None):
+            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, tag=None):
     """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
     bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD (out=None, stats given:
     statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator."""
@@ -203,7 +203,8 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
         sc, sh, mean, rstd, mask, inv_keep = bn
         g.bn_scale, g.bn_shift, g.bn_mean, g.bn_rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         g.epi_mask, g.ld_epi_mask, g.epi_inv_keep = _p(mask), (_ld(mask) if mask is not None else 0), inv_keep
-        g.bn_coef, g.bn_phase = _p(bn_coef), int(bn_coef is not None)
+        g.bn_coef = _p(bn_coef)
+        g.bn_phase = bn_phase if bn_phase is not None else int(bn_coef is not None)
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.shape[0] == 2 and stats.shape[1] >= N and stats.stride(1) == 1
         g.stat1, g.stat2 = stats[0].data_ptr(), stats[1].data_ptr()
@@ -265,6 +266,11 @@ def bn_bwd_finalize(M, N, stats, gamma, rstd, dgamma, dbeta, coef):
     a = L.BnBwdFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
                             gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr())
     L.check(L.load().mmvae_bn_bwd_finalize(C.byref(a), _stream()), "mmvae_bn_bwd_finalize")
+
+
+def bn_bwd_apply(d, y, N, mean, rstd, coef):
+    L.check(L.load().mmvae_bn_bwd_apply(_dt(d), d.shape[0], N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y),
+                                        mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), _stream()), "mmvae_bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------
