@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-probe", action="store_true", help="do not bracket GEMM launches with events")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,11 +105,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from mmvae import ops, parallel
     from mmvae.optim import FusedAdamW

@@ -37,6 +37,8 @@ enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 #define MMVAE_TILE 128          /* GEMM output tile edge */
 
 int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
+/* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernel (default 32768). */
+int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight preparation: fp32 master weights -> zero-padded MFMA operand copies (compute type),

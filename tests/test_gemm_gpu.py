@@ -156,3 +156,66 @@ def test_bn_relu_drop_prologue_and_bwd_epilogues(prec, with_mask):
     refy = coef[0].double() * (refd - coef[1].double() - xhat * coef[2].double())
     got = outd.float().cpu().double()
     assert float((got - refy).abs().max()) <= _tol(N, float(refy.abs().max()), prec == PREC_BF16)
+
+
+@pytest.mark.parametrize("N,K", [(256, 512), (512, 572), (512, 256)])
+def test_nt_wide_tiles(N, K):
+    """The 128x256-tile / 8-wave NT kernel (normally used from 256 row tiles up) at a small ragged M, all epilogues."""
+    from mmvae import _lib
+    lib = _lib.load()
+    lib.mmvae_set_tuning(0, 1)
+    try:
+        prec, M = PREC_BF16, 389
+        g = torch.Generator().manual_seed(N + K)
+        A = _round(torch.randn(M, K, generator=g), prec)
+        W = torch.randn(N, K, generator=g) / np.sqrt(K)
+        b = torch.randn(N, generator=g)
+        pl = _prep(W.to(DEV), b.to(DEV), prec)
+        ref = A.double() @ _round(W, prec).double().t() + b.double()
+        for Ad in (A.to(DEV), torch.nn.functional.pad(A, (0, ops.ceil_to(K, 8) - K)).to(DEV).bfloat16()):
+            for out_dt in (torch.float32, torch.bfloat16):
+                out = torch.full((M, N), 7.0, dtype=out_dt, device=DEV)
+                st = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+                ops.gemm_nt(prec, Ad, pl.w, N, K, out, bias=pl.bias, act=ops.ACT_RELU, stats=st)
+                r = ref.clamp_min(0)
+                got = out.float().cpu().double()
+                assert float((got - r).abs().max()) <= _tol(K, float(r.abs().max()), out_dt == torch.bfloat16)
+                np.testing.assert_allclose(st[0].cpu(), got.sum(0), rtol=1e-4, atol=1e-2)
+        # backward epilogues on the wide kernel: ReLU mask and both BatchNorm forms (output width N, reduction K)
+        adt = torch.bfloat16
+        dY = _round(torch.randn(M, K, generator=g), prec)
+        Wt = torch.randn(N, K, generator=g) / np.sqrt(K)           # plays W^T: [N out][K red]
+        plt = _prep(Wt.to(DEV), torch.zeros(N, device=DEV), prec)
+        base = dY.double() @ _round(Wt, prec).double().t()
+        H = _round(torch.relu(torch.randn(M, N, generator=g)), prec)
+        outd = torch.zeros(M, N, dtype=adt, device=DEV)
+        dYd = torch.nn.functional.pad(dY, (0, ops.ceil_to(K, 8) - K)).to(DEV).to(adt)      # activation buffers have 8-element rows
+        ops.gemm_nt(prec, dYd, plt.w, N, K, outd, epilogue=ops.EPI_RELU_MASK, h=H.to(DEV).to(adt))
+        refd = base * (H > 0)
+        assert float((outd.float().cpu().double() - refd).abs().max()) <= _tol(K, float(refd.abs().max()), True)
+        y = _round(torch.randn(M, N, generator=g), prec)
+        scale, shift = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.3
+        mean, rstd = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5
+        mask = (torch.rand(M, N, generator=g) < 0.9).to(torch.uint8)
+        bnargs = (scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), mask.to(DEV), 1.0 / 0.9)
+        st = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+        ops.gemm_nt(prec, dYd, plt.w, N, K, outd, epilogue=ops.EPI_BN_BWD, h=y.to(DEV).to(adt), bn=bnargs, bn_phase=2, stats=st)
+        d = base * (mask.double() / 0.9) * ((y * scale + shift) > 0)
+        xhat = (y.double() - mean.double()) * rstd.double()
+        assert float((outd.float().cpu().double() - d).abs().max()) <= _tol(K, float(d.abs().max()), True)
+        np.testing.assert_allclose(st[0].cpu(), d.sum(0), rtol=1e-4, atol=2e-2)
+        np.testing.assert_allclose(st[1].cpu(), (d * xhat).sum(0), rtol=1e-4, atol=4e-2)
+        # BN prologue on the A operand with the wide kernel
+        Kp = 256
+        yp = _round(torch.randn(M, Kp, generator=g), prec)
+        sc, sh = torch.rand(Kp, generator=g) + 0.5, torch.randn(Kp, generator=g) * 0.3
+        mk = (torch.rand(M, Kp, generator=g) < 0.9).to(torch.uint8)
+        W2 = torch.randn(N, Kp, generator=g) / 16
+        pl2 = _prep(W2.to(DEV), b.to(DEV), prec)
+        hq = _round(torch.relu(yp * sc + sh) * mk.float() / 0.9, prec)
+        ref2 = hq.double() @ _round(W2, prec).double().t() + b.double()
+        out2 = torch.zeros(M, N, device=DEV)
+        ops.gemm_nt(prec, yp.to(DEV).to(adt), pl2.w, N, Kp, out2, bias=pl2.bias, prologue=(sc.to(DEV), sh.to(DEV), mk.to(DEV), 1.0 / 0.9))
+        assert float((out2.cpu().double() - ref2).abs().max()) <= _tol(Kp, float(ref2.abs().max()))
+    finally:
+        lib.mmvae_set_tuning(0, 256 * 128)

@@ -29,22 +29,29 @@ namespace mm {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
-constexpr int NT_STAGE_BYTES = 3 * TILE * ROW_BYTES;    // 48 KiB: main loop uses 32 (A,W); epilogue up to 32 + 16 (mask)
+// LDS: main loop A [128][128 B] + W [64*WN][128 B]; the epilogue reuses it as scratch (2-byte tile [128][64*WN] + mask bytes)
+template <int WN> struct NtLds {
+    static constexpr int MAIN = (TILE + 64 * WN) * ROW_BYTES;
+    static constexpr int SCRATCH = TILE * 64 * WN * 3;            // 48 KiB (WN=2) / 96 KiB (WN=4)
+    static constexpr int STAGE = MAIN > SCRATCH ? MAIN : SCRATCH;
+    static constexpr int TOTAL = STAGE + 4096 + 4 * 64 * WN * 4;   // + BN prologue scale/shift + column-sum scratch
+};
 
-template <typename CT, typename Src, typename Epi>
-__global__ __launch_bounds__(NTHREADS, 2)
+// WN = 2: 128x128 tile, 4 waves, 2 workgroups per CU.  WN = 4: 128x256 tile, 8 waves, 1 workgroup per CU -- the A tile is
+// fetched once for 256 output columns, which halves the L2->CU operand ingest of the N = 256 / 512 layers.
+template <typename CT, typename Src, typename Epi, int WN>
+__global__ __launch_bounds__(128 * WN, 2)
 void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
 {
     constexpr int EPC = Mma<CT>::EPC;
     constexpr int BK = ROW_BYTES / (int)sizeof(CT);
+    constexpr int BN = 64 * WN, NTH = 128 * WN, A_PER = 8 / WN;
     typedef typename Mma<CT>::frag frag;
-    typedef typename Epi::out_t OT;
-    typedef typename Epi::h_t HT;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NT_STAGE_BYTES + 4096 + 2048];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
     unsigned char* sB = smem + TILE * ROW_BYTES;
-    float* aux = (float*)(smem + NT_STAGE_BYTES);
-    float* red = (float*)(smem + NT_STAGE_BYTES + 4096);
+    float* aux = (float*)(smem + NtLds<WN>::STAGE);
+    float* red = (float*)(smem + NtLds<WN>::STAGE + 4096);
 
     // XCD-aware tile assignment: linear id L runs on XCD L%8 (round-robin dispatch, speed only).
     const int L = blockIdx.x;
@@ -52,10 +59,10 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     const int ct = slot % gy;
     const int rt = (slot / gy) * 8 + (L & 7);
     if (rt >= gx) return;
-    const int row0 = rt * TILE, col0 = ct * TILE;
+    const int row0 = rt * TILE, col0 = ct * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WN, wc = wid % WN;
 
     if (Src::NEEDS_AUX) { src.init(aux, tid); __syncthreads(); }
 
@@ -65,36 +72,39 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    typename Src::Raw ra[4];
-    Chunk<CT> rb[4];
+    // TWO register sets: while K step kt is multiplied, the loads of kt+1 AND kt+2 are in flight (one step of look-ahead
+    // left every step waiting a full L2/HBM round trip: the loop was latency-bound, not byte-bound).
+    typename Src::Raw ra0[A_PER], ra1[A_PER];
+    Chunk<CT> rb0[4], rb1[4];
     const int nk = (K + BK - 1) / BK;
-    EpiPrefetch pf;
-    if (!epi.accum()) nt_epilogue_prefetch<CT>(pf, epi, row0, col0, M, N, tid);
 
-    auto fetch = [&](int kt) {
+    auto fetch = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int c = tid + NTH * i, r = c >> 3, ch = c & 7;
+            src.fetch(ra[i], row0 + r, kt * BK + ch * EPC);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
-            src.fetch(ra[i], row0 + r, kt * BK + ch * EPC);
+            int c = tid + NTH * i, r = c >> 3, ch = c & 7;
             rb[i].v = *(const decltype(rb[i].v)*)(W + (long)(col0 + r) * ldw + kt * BK + ch * EPC);
         }
     };
-    auto stage = [&](int kt) {
+    auto stage = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
+        for (int i = 0; i < A_PER; ++i) {
+            int c = tid + NTH * i, r = c >> 3, ch = c & 7;
             Chunk<CT> o;
             src.finish(ra[i], row0 + r, kt * BK + ch * EPC, o, aux);
             *(decltype(o.v)*)(sA + swz(r, ch)) = o.v;
-            *(decltype(o.v)*)(sB + swz(r, ch)) = rb[i].v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + NTH * i, r = c >> 3, ch = c & 7;
+            *(decltype(rb[i].v)*)(sB + swz(r, ch)) = rb[i].v;
         }
     };
-
-    fetch(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        stage(kt);
-        __syncthreads();
-        if (kt + 1 < nk) fetch(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             frag af[4], bf[4];
@@ -108,10 +118,28 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
 #pragma unroll
                 for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], af[m], bf[n]);
         }
+    };
+
+    fetch(ra0, rb0, 0);
+    if (nk > 1) fetch(ra1, rb1, 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        stage(ra0, rb0, kt);
         __syncthreads();
+        if (kt + 2 < nk) fetch(ra0, rb0, kt + 2);
+        compute();
+        __syncthreads();
+        if (kt + 1 < nk) {
+            stage(ra1, rb1, kt + 1);
+            __syncthreads();
+            if (kt + 3 < nk) fetch(ra1, rb1, kt + 3);
+            compute();
+            __syncthreads();
+        }
     }
 
-    nt_epilogue<CT>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
+    EpiPrefetch pf;                      // epilogue operand tiles (fetched here: the two K-step register sets take the VGPR room)
+    if (!epi.accum()) nt_epilogue_prefetch<CT, Epi, WN>(pf, epi, row0, col0, M, N, tid);
+    nt_epilogue<CT, Epi, WN>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
 }
 
 struct RingSrc { const void* a; long lda; };     // tag: plain bf16 A served by the LDS-ring kernel (gemm_ring.h)
@@ -122,14 +150,35 @@ static int launch_nt(const RingSrc& src, const void* W, long ldw, int M, int N, 
     return MMVAE_ERR_DTYPE;
 }
 
-template <typename CT, typename Src, typename Epi>
-static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
-    int gx = (M + TILE - 1) / TILE, gy = (N + TILE - 1) / TILE;
-    int grid = ((gx + 7) / 8) * 8 * gy;
-    hipLaunchKernelGGL((gemm_nt_kernel<CT, Src, Epi>), dim3(grid), dim3(NTHREADS), 0, st,
+template <typename CT, typename Src, typename Epi, int WN>
+static int launch_nt_wn(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<CT, Src, Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, NtLds<WN>::TOTAL);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int gx = (M + TILE - 1) / TILE, gy = (N + 64 * WN - 1) / (64 * WN);
+    const int grid = ((gx + 7) / 8) * 8 * gy;
+    hipLaunchKernelGGL((gemm_nt_kernel<CT, Src, Epi, WN>), dim3(grid), dim3(128 * WN), NtLds<WN>::TOTAL, st,
                        src, (const CT*)W, ldw, M, N, K, gx, gy, epi);
     MM_CHECK_LAUNCH();
     return 0;
+}
+
+static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >= 256 row tiles (mmvae_set_tuning key 0)
+
+static inline bool nt_wide_ok(int M, int N) {
+    static const bool off = getenv("MMVAE_NO_WIDE_TILES") != nullptr;      // A/B switch
+    return !off && N % 256 == 0 && M >= g_wide_min_m;       // the prepared W has ceil128(N) rows: whole 256-column tiles only
+}
+
+template <typename CT, typename Src, typename Epi>
+static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    if constexpr (sizeof(CT) == 2) {
+        if (nt_wide_ok(M, N) && !epi.accumulate_requested()) return launch_nt_wn<CT, Src, Epi, 4>(src, W, ldw, M, N, K, epi, st);
+    }
+    return launch_nt_wn<CT, Src, Epi, 2>(src, W, ldw, M, N, K, epi, st);
 }
 
 template <typename CT, typename Src>
@@ -218,6 +267,11 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
 }
 
 }  // namespace mm
+
+extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
+    if (key == 0) { mm::g_wide_min_m = value; return 0; }
+    return MMVAE_ERR_ARG;
+}
 
 extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     if (!a || !a->a || !a->w || (!a->c && !(a->epilogue == MMVAE_EPI_BN_BWD && a->bn_phase == 0))) return MMVAE_ERR_ARG;

@@ -22,6 +22,7 @@ struct EpiStore {               // C = act(acc + bias) (+ C) ; stats = (sum C, s
     struct Col { float b; };
     __device__ __forceinline__ bool stores() const { return true; }
     __device__ __forceinline__ bool accum() const { return accumulate != 0; }
+    bool accumulate_requested() const { return accumulate != 0; }
     __device__ __forceinline__ Col col(int c, int N) const { return Col{(bias && c < N) ? bias[c] : 0.f}; }
     __device__ __forceinline__ float compute(float v, float, unsigned, const Col& cc, bool count, float& s1, float& s2) const {
         v += cc.b;
@@ -43,6 +44,7 @@ struct EpiReluMask {            // dH = (H > 0) ? acc : 0
     struct Col {};
     __device__ __forceinline__ bool stores() const { return true; }
     __device__ __forceinline__ bool accum() const { return false; }
+    bool accumulate_requested() const { return false; }
     __device__ __forceinline__ Col col(int, int) const { return Col{}; }
     __device__ __forceinline__ float compute(float v, float h, unsigned, const Col&, bool, float&, float&) const {
         return h > 0.f ? v : 0.f;
@@ -66,6 +68,7 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     struct Col { float sc, sh, mu, rs, c0, c1, c2; };
     __device__ __forceinline__ bool stores() const { return phase != 0; }
     __device__ __forceinline__ bool accum() const { return false; }
+    bool accumulate_requested() const { return false; }
     __device__ __forceinline__ Col col(int c, int N) const {
         Col k{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (c < N) {
@@ -87,13 +90,16 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
 // so that their HBM latency is hidden under the contraction instead of being exposed between main loop and stores.
 struct EpiPrefetch { f32x4 h[8]; f32x4 m[4]; };
 
-template <typename CT, typename Epi>
+// WN = waves along N: the tile is 128 x (64*WN), owned by 2*WN waves (128*WN threads).  The per-thread chunk counts of the
+// cooperative tile loads/stores below are independent of WN (8 x 16 B of a 2-byte tile, 4 x 16 B of the mask).
+template <typename CT, typename Epi, int WN = 2>
 __device__ __forceinline__ void nt_epilogue_prefetch(EpiPrefetch& pf, const Epi& epi, int row0, int col0, int M, int N, int tid) {
     typedef typename Epi::h_t HT;
+    constexpr int BN = 64 * WN, NTH = 128 * WN;
     if constexpr (sizeof(CT) == 2 && Epi::NEED >= 1 && sizeof(HT) == 2) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c = tid + NTHREADS * i, r = c >> 4, ch = c & 15;
+            const int c = tid + NTH * i, r = c / (BN / 8), ch = c % (BN / 8);
             const int gr = row0 + r, gc = col0 + ch * 8;
             pf.h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (gr < M && gc < N) pf.h[i] = *(const f32x4*)(epi.H + (long)gr * epi.ldh + gc);     // rows padded to 8 elements
@@ -101,7 +107,7 @@ __device__ __forceinline__ void nt_epilogue_prefetch(EpiPrefetch& pf, const Epi&
         if (Epi::NEED >= 2 && epi.mask != nullptr) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
+                const int c = tid + NTH * i, r = c / (BN / 16), ch = c % (BN / 16);
                 const int gr = row0 + r, gc = col0 + ch * 16;
                 pf.m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (gr < M && gc < N) pf.m[i] = *(const f32x4*)(epi.mask + (long)gr * epi.ldm + gc);   // N % 16 == 0 checked on the host
@@ -110,11 +116,12 @@ __device__ __forceinline__ void nt_epilogue_prefetch(EpiPrefetch& pf, const Epi&
     }
 }
 
-// smem: >= 48 KiB scratch (free to overwrite), red: 2 KiB.  wr/wc: wave row/column inside the tile.
-template <typename CT, typename Epi>
+// smem: >= 24 KiB * WN scratch (free to overwrite), red: 1 KiB * WN.  wr/wc: wave row/column inside the tile.
+template <typename CT, typename Epi, int WN = 2>
 __device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32x4 (&acc)[4][4], const Epi& epi, const EpiPrefetch& pf,
                                             int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
 {
+    constexpr int BN = 64 * WN, NTH = 128 * WN, RB = BN * 2;      // RB: row bytes of a staged 2-byte tile
     typedef typename Epi::out_t OT;
     typedef typename Epi::h_t HT;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -124,18 +131,18 @@ __device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32
     constexpr bool CAN_STAGE = sizeof(CT) == 2 && (Epi::NEED == 0 || sizeof(HT) == 2);
     if (CAN_STAGE && !epi.accum()) {
         unsigned char* sT = smem;                               // [128][128] of a 2-byte type, or [64][128] f32
-        unsigned char* sM = smem + 2 * TILE * ROW_BYTES;        // [128][128] mask bytes
+        unsigned char* sM = smem + TILE * RB;                    // [128][BN] mask bytes
         if (Epi::NEED >= 1) {                                   // operand tiles: registers (prefetched) -> LDS
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int c = tid + NTHREADS * i, r = c >> 4, ch = c & 15;
-                *(f32x4*)(sT + r * 256 + ch * 16) = pf.h[i];
+                const int c = tid + NTH * i, r = c / (BN / 8), ch = c % (BN / 8);
+                *(f32x4*)(sT + r * RB + ch * 16) = pf.h[i];
             }
             if (Epi::NEED >= 2 && epi.mask != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int c = tid + NTHREADS * i, r = c >> 3, ch = c & 7;
-                    *(f32x4*)(sM + r * 128 + ch * 16) = pf.m[i];
+                    const int c = tid + NTH * i, r = c / (BN / 16), ch = c % (BN / 16);
+                    *(f32x4*)(sM + r * BN + ch * 16) = pf.m[i];
                 }
             }
             __syncthreads();
@@ -155,27 +162,27 @@ __device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32
                             const int rl = wr * 64 + m * 16 + lg * 4 + j;
                             const bool ok = (row0 + rl < M) && (c < N);
                             float hv = 0.f; unsigned mb = 1;
-                            if (Epi::NEED >= 1) hv = to_f32(*(const HT*)(sT + rl * 256 + cl * 2));
-                            if (Epi::NEED >= 2) mb = sM[rl * 128 + cl];
+                            if (Epi::NEED >= 1) hv = to_f32(*(const HT*)(sT + rl * RB + cl * 2));
+                            if (Epi::NEED >= 2) mb = sM[rl * BN + cl];
                             float o = epi.compute(acc[m][n][j], hv, mb, cc, ok, s1[n], s2[n]);
                             if (c >= N) o = 0.f;
                             const int rs = HALVES == 1 ? rl : rl - hf * 64;
-                            *(OT*)(sT + (rs * TILE + cl) * (int)sizeof(OT)) = from_f32<OT>(o);
+                            *(OT*)(sT + (rs * BN + cl) * (int)sizeof(OT)) = from_f32<OT>(o);
                         }
                 }
             }
             if (epi.stores()) {
                 __syncthreads();
-                constexpr int CPR = TILE * (int)sizeof(OT) / 16, EPCO = 16 / (int)sizeof(OT);
+                constexpr int CPR = BN * (int)sizeof(OT) / 16, EPCO = 16 / (int)sizeof(OT);
                 const bool v16 = ((epi.ldc * sizeof(OT)) % 16 == 0) && (((uintptr_t)epi.C & 15) == 0);
                 const bool v8 = ((epi.ldc * sizeof(OT)) % 8 == 0) && (((uintptr_t)epi.C & 7) == 0);
                 const int n_store = (int)min((long)((N + EPCO - 1) / EPCO * EPCO), epi.ldc);   // pad columns of internal buffers get zeros
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int c = tid + NTHREADS * i, r = c / CPR, ch = c % CPR;
+                    const int c = tid + NTH * i, r = c / CPR, ch = c % CPR;
                     const int gr = row0 + hf * (TILE / HALVES) + r, gc = col0 + ch * EPCO;
                     if (gr >= M || gc >= n_store) continue;
-                    const unsigned char* sp = sT + r * (TILE * (int)sizeof(OT)) + ch * 16;
+                    const unsigned char* sp = sT + r * (BN * (int)sizeof(OT)) + ch * 16;
                     OT* gp = epi.C + (long)gr * epi.ldc + gc;
                     if (gc + EPCO <= n_store && v16) *(f32x4*)gp = *(const f32x4*)sp;
                     else if (gc + EPCO <= n_store && v8) { ((f32x2*)gp)[0] = ((const f32x2*)sp)[0]; ((f32x2*)gp)[1] = ((const f32x2*)sp)[1]; }
@@ -220,14 +227,14 @@ __device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32
             s1[n] += __shfl_xor(s1[n], 16, 64); s1[n] += __shfl_xor(s1[n], 32, 64);
             s2[n] += __shfl_xor(s2[n], 16, 64); s2[n] += __shfl_xor(s2[n], 32, 64);
             if (lane < 16) {
-                red[(wr * 2 + 0) * TILE + wc * 64 + n * 16 + lane] = s1[n];
-                red[(wr * 2 + 1) * TILE + wc * 64 + n * 16 + lane] = s2[n];
+                red[(wr * 2 + 0) * BN + wc * 64 + n * 16 + lane] = s1[n];
+                red[(wr * 2 + 1) * BN + wc * 64 + n * 16 + lane] = s2[n];
             }
         }
         __syncthreads();
-        if (tid < TILE && col0 + tid < N) {
-            if (epi.stat1) unsafeAtomicAdd(epi.stat1 + col0 + tid, (double)(red[0 * TILE + tid] + red[2 * TILE + tid]));
-            if (epi.stat2) unsafeAtomicAdd(epi.stat2 + col0 + tid, (double)(red[1 * TILE + tid] + red[3 * TILE + tid]));
+        if (tid < BN && col0 + tid < N) {
+            if (epi.stat1) unsafeAtomicAdd(epi.stat1 + col0 + tid, (double)(red[0 * BN + tid] + red[2 * BN + tid]));
+            if (epi.stat2) unsafeAtomicAdd(epi.stat2 + col0 + tid, (double)(red[1 * BN + tid] + red[3 * BN + tid]));
         }
     }
 }

@@ -79,7 +79,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, long lda, unsigned a_bytes,
 
     const int nk = (K + 63) / 64;
     EpiPrefetch pf;
-    if (!epi.accum()) nt_epilogue_prefetch<bf16>(pf, epi, row0, col0, M, N, tid);
+    if (!epi.accum()) nt_epilogue_prefetch<bf16, Epi, 2>(pf, epi, row0, col0, M, N, tid);
 #pragma unroll
     for (int s = 0; s < RING_NS - 1; ++s) if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
@@ -104,7 +104,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, long lda, unsigned a_bytes,
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     ring_barrier();                                       // ring is free: the epilogue reuses it as scratch
-    nt_epilogue<bf16>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
+    nt_epilogue<bf16, Epi, 2>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
 }
 
 template <typename Epi>

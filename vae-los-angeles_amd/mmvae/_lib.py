@@ -100,6 +100,7 @@ class AdamWItem(C.Structure):
 
 # name -> (argtypes); every function returns int and takes the stream last
 _SIGNATURES = {
+    "mmvae_set_tuning": [i32, i32],
     "mmvae_prep_weights": [vp, i32, vp],
     "mmvae_gemm_nt": [C.POINTER(GemmNtArgs), vp],
     "mmvae_gemm_tn": [C.POINTER(GemmTnArgs), vp],
