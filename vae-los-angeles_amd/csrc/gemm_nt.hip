@@ -29,9 +29,10 @@ namespace mm {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
-// LDS: main loop A [128][128 B] + W [64*WN][128 B]; the epilogue reuses it as scratch (2-byte tile [128][64*WN] + mask bytes)
+// LDS: main loop 2 x { A [128][128 B] + W [64*WN][128 B] }; the epilogue reuses it as scratch (2-byte tile [128][64*WN] + mask bytes)
 template <int WN> struct NtLds {
-    static constexpr int MAIN = (TILE + 64 * WN) * ROW_BYTES;
+    static constexpr int BUF = (TILE + 64 * WN) * ROW_BYTES;      // one K step of A and W
+    static constexpr int MAIN = 2 * BUF;                          // double buffered
     static constexpr int SCRATCH = TILE * 64 * WN * 3;            // 48 KiB (WN=2) / 96 KiB (WN=4)
     static constexpr int STAGE = MAIN > SCRATCH ? MAIN : SCRATCH;
     static constexpr int TOTAL = STAGE + 4096 + 4 * 64 * WN * 4;   // + BN prologue scale/shift + column-sum scratch
@@ -48,8 +49,6 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     constexpr int BN = 64 * WN, NTH = 128 * WN, A_PER = 8 / WN;
     typedef typename Mma<CT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + TILE * ROW_BYTES;
     float* aux = (float*)(smem + NtLds<WN>::STAGE);
     float* red = (float*)(smem + NtLds<WN>::STAGE + 4096);
 
@@ -90,7 +89,9 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
             rb[i].v = *(const decltype(rb[i].v)*)(W + (long)(col0 + r) * ldw + kt * BK + ch * EPC);
         }
     };
-    auto stage = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt) {
+    auto stage = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt, int buf) {      // registers -> LDS buffer
+        unsigned char* sA = smem + buf * NtLds<WN>::BUF;
+        unsigned char* sB = sA + TILE * ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int c = tid + NTH * i, r = c >> 3, ch = c & 7;
@@ -104,35 +105,93 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
             *(decltype(rb[i].v)*)(sB + swz(r, ch)) = rb[i].v;
         }
     };
-    auto compute = [&]() {
+    auto compute = [&](int buf, int s) {                      // fragment step s (0/1) of an LDS buffer
+        const unsigned char* sA = smem + buf * NtLds<WN>::BUF;
+        const unsigned char* sB = sA + TILE * ROW_BYTES;
+        frag af[4], bf[4];
+        const int ch = s * 4 + (lane >> 4);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            frag af[4], bf[4];
-            const int ch = s * 4 + (lane >> 4);
+        for (int m = 0; m < 4; ++m) af[m] = *(const frag*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *(const frag*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
+        for (int n = 0; n < 4; ++n) bf[n] = *(const frag*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = *(const frag*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], af[m], bf[n]);
-        }
+            for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], af[m], bf[n]);
     };
 
-    fetch(ra0, rb0, 0);
-    if (nk > 1) fetch(ra1, rb1, 1);
-    for (int kt = 0; kt < nk; kt += 2) {
-        stage(ra0, rb0, kt);
+    // Double-buffered LDS, ONE barrier per K step: while buffer kt&1 is multiplied, tile kt+1 is written into the other
+    // buffer between the two fragment steps and tiles kt+2 / kt+3 are in flight from HBM/L2 in the two register sets.
+    //
+    // hipcc's s_waitcnt insertion is only as precise as the control flow lets it be: a fetch under `if (kt + 3 < nk)`
+    // means "maybe 8 fewer loads in flight" at the next stage(), and the wait degrades to vmcnt(0) -- every K step then
+    // drains BOTH register sets and the look-ahead is gone (this is what made load phase + MFMA phase add up).  So the
+    // steady-state loop below has NO conditional fetches and is entered only with both sets in flight; the last 3-4
+    // K steps and the short-K layers (nk <= 4) run the conditional form.
+    if (nk >= 5) {
+        fetch(ra0, rb0, 0);
+        fetch(ra1, rb1, 1);
+        stage(ra0, rb0, 0, 0);
+        fetch(ra0, rb0, 2);
         __syncthreads();
-        if (kt + 2 < nk) fetch(ra0, rb0, kt + 2);
-        compute();
-        __syncthreads();
-        if (kt + 1 < nk) {
-            stage(ra1, rb1, kt + 1);
+        int kt = 0;
+        for (; kt + 4 < nk; kt += 2) {
+            compute(0, 0);
+            stage(ra1, rb1, kt + 1, 1);
+            compute(0, 1);
+            fetch(ra1, rb1, kt + 3);
             __syncthreads();
-            if (kt + 3 < nk) fetch(ra1, rb1, kt + 3);
-            compute();
+            compute(1, 0);
+            stage(ra0, rb0, kt + 2, 0);
+            compute(1, 1);
+            fetch(ra0, rb0, kt + 4);
+            __syncthreads();
+        }
+        const bool four = kt + 3 < nk;                        // 3 or 4 K steps left: kt in LDS, kt+1 / kt+2 in flight
+        compute(0, 0);
+        stage(ra1, rb1, kt + 1, 1);
+        compute(0, 1);
+        if (four) fetch(ra1, rb1, kt + 3);
+        __syncthreads();
+        compute(1, 0);
+        stage(ra0, rb0, kt + 2, 0);
+        compute(1, 1);
+        __syncthreads();
+        compute(0, 0);
+        if (four) stage(ra1, rb1, kt + 3, 1);
+        compute(0, 1);
+        __syncthreads();
+        if (four) {
+            compute(1, 0);
+            compute(1, 1);
+            __syncthreads();
+        }
+    } else {
+        fetch(ra0, rb0, 0);
+        if (nk > 1) fetch(ra1, rb1, 1);
+        stage(ra0, rb0, 0, 0);
+        if (nk > 2) fetch(ra0, rb0, 2);
+        __syncthreads();
+        compute(0, 0);
+        if (nk > 1) stage(ra1, rb1, 1, 1);
+        compute(0, 1);
+        if (nk > 3) fetch(ra1, rb1, 3);
+        __syncthreads();
+        if (nk > 1) {
+            compute(1, 0);
+            if (nk > 2) stage(ra0, rb0, 2, 0);
+            compute(1, 1);
+            __syncthreads();
+        }
+        if (nk > 2) {
+            compute(0, 0);
+            if (nk > 3) stage(ra1, rb1, 3, 1);
+            compute(0, 1);
+            __syncthreads();
+        }
+        if (nk > 3) {
+            compute(1, 0);
+            compute(1, 1);
             __syncthreads();
         }
     }

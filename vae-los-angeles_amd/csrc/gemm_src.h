@@ -19,17 +19,14 @@ template <int EPC> struct RawVec<float, EPC> {
     __device__ __forceinline__ float get(int i) const { return v[i]; }
 };
 
+// Every fetch below is BRANCH-FREE: the address is clamped into the tensor and the load always issues; rows past M and
+// columns past K are zeroed in finish(), after the wait the compiler places at the first use.  An `if (ok) load else zero`
+// makes hipcc wrap each load in an exec-masked block whose else-side writes the same VGPRs, which forces an
+// s_waitcnt vmcnt(0) after every load and serialises the whole K-step prefetch (seen in the gfx950 ISA).
 template <int EPC, int VEC>
-__device__ __forceinline__ void load_chunk_f32(RawVec<float, EPC>& r, const float* p, int k, int K, bool row_ok) {
+__device__ __forceinline__ void load_chunk_f32(RawVec<float, EPC>& r, const float* row_ptr, int k, int K) {
 #pragma unroll
-    for (int j = 0; j < EPC; j += VEC) {
-        if (row_ok && k + j < K) {
-            VLoad<float, VEC>::ld(p + j, &r.v[j]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r.v[j + e] = 0.f;
-        }
-    }
+    for (int j = 0; j < EPC; j += VEC) VLoad<float, VEC>::ld(row_ptr + min(k + j, K - VEC), &r.v[j]);     // K % VEC == 0, K >= VEC
 }
 
 // Plain A[M][K] (element type AT, row stride lda, vectors of VEC elements; K % VEC == 0).
@@ -41,26 +38,25 @@ struct SrcPlain {
     typedef RawVec<AT, EPC> Raw;
     __device__ __forceinline__ void init(float*, int) const {}
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {
-        bool ok = row < M;
-        const AT* q = p + (long)row * lda + k;
+        const AT* q = p + (long)min(row, M - 1) * lda;
         if constexpr (sizeof(AT) == 2) {
-            if (ok && k < K) {
-                r.v = *(const bf16x8*)q;                 // internal buffers: rows padded to 8 elements
-                if (k + 8 > K) {                         // never let pad garbage meet the zero weights
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) if (k + i >= K) r.v[i] = (bf16)0.f;
-                }
-            } else r.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            r.v = *(const bf16x8*)(q + min(k, ((K + 7) & ~7) - 8));      // internal buffers: rows padded to 8 elements
         } else {
-            load_chunk_f32<EPC, VEC>(r, q, k, K, ok);
+            load_chunk_f32<EPC, VEC>(r, q, k, K);
         }
     }
-    __device__ __forceinline__ void finish(const Raw& r, int, int, Chunk<CT>& o, const float*) const {
+    __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float*) const {
+        const bool ok = row < M;
         if constexpr (sizeof(AT) == 2) {
-            o.v = r.v;
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            o.v = (ok && k < K) ? r.v : z;
+            if (k + 8 > K) {                             // never let pad garbage meet the zero weights
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (k + i >= K) o.v[i] = (bf16)0.f;
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) o.set(i, r.v[i]);
+            for (int i = 0; i < EPC; ++i) o.set(i, (ok && k + i < K) ? r.v[i] : 0.f);
         }
     }
 };
@@ -79,22 +75,21 @@ struct SrcBnReluDrop {
     __device__ __forceinline__ void init(float* aux, int tid) const {
         for (int i = tid; i < K; i += NTHREADS) { aux[i] = scale[i]; aux[512 + i] = shift[i]; }
     }
-    __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {
-        bool ok = row < M && k < K;
-        const CT* q = y + (long)row * ldy + k;
+    __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {        // K % EPC == 0 (hidden widths)
+        const int rc = min(row, M - 1), kc = min(k, K - EPC);
+        const CT* q = y + (long)rc * ldy + kc;
         if constexpr (sizeof(CT) == 2) {
-            if (ok) r.y.v = *(const bf16x8*)q; else r.y.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            r.y.v = *(const bf16x8*)q;
         } else {
-            if (ok) { f32x4 t = *(const f32x4*)q; r.y.v[0] = t[0]; r.y.v[1] = t[1]; r.y.v[2] = t[2]; r.y.v[3] = t[3]; }
-            else { r.y.v[0] = r.y.v[1] = r.y.v[2] = r.y.v[3] = 0.f; }
+            f32x4 t = *(const f32x4*)q; r.y.v[0] = t[0]; r.y.v[1] = t[1]; r.y.v[2] = t[2]; r.y.v[3] = t[3];
         }
-        if (mask != nullptr && ok) {
-            const uint32_t* mp = (const uint32_t*)(mask + (long)row * ldm + k);
+        if (mask != nullptr) {                           // kernel-argument uniform: a scalar branch
+            const uint32_t* mp = (const uint32_t*)(mask + (long)rc * ldm + kc);
 #pragma unroll
             for (int i = 0; i < EPC / 4; ++i) r.m[i] = mp[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < EPC / 4; ++i) r.m[i] = mask != nullptr ? 0u : 0x01010101u;
+            for (int i = 0; i < EPC / 4; ++i) r.m[i] = 0x01010101u;
         }
     }
     __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const {
