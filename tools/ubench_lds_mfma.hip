@@ -35,18 +35,19 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
         for (int m = 0; m < 4; ++m) { af[m] = *(const bf16x8*)(sA + swz(wr * 64 + m * 16 + (lane & 15), lane >> 4)); bf[m] = af[m]; }
         unsigned x = 0;
         for (int it = 0; it < iters; ++it) {
+            asm volatile("" ::: "memory");                    // re-read LDS every iteration
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int ch = s * 4 + (lane >> 4);
                 if constexpr (V != 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) af[m] = *(const volatile bf16x8*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
+                    for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) bf[n] = *(const volatile bf16x8*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
+                    for (int n = 0; n < 4; ++n) bf[n] = *(const bf16x8*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
                 }
                 if constexpr (V == 1) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) { typedef __attribute__((ext_vector_type(4))) unsigned u4; u4 a = (u4)af[m], b = (u4)bf[m]; x ^= a[0] ^ b[3]; }
+                    for (int m = 0; m < 4; ++m) asm volatile("" :: "v"(af[m]), "v"(bf[m]));     // consume, no ALU work
                 } else {
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -64,14 +65,15 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
         bf16x8 af[2], bf[2];
         for (int m = 0; m < 2; ++m) { af[m] = *(const bf16x8*)(sA + swz(wr * 64 + m * 32 + (lane & 31), lane >> 5)); bf[m] = af[m]; }
         for (int it = 0; it < iters; ++it) {
+            asm volatile("" ::: "memory");                    // re-read LDS every iteration
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                       // 4 k-slices of 16
                 const int ch = s * 2 + (lane >> 5);
                 if constexpr (V == 3) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = *(const volatile bf16x8*)(sA + swz(wr * 64 + m * 32 + (lane & 31), ch));
+                    for (int m = 0; m < 2; ++m) af[m] = *(const bf16x8*)(sA + swz(wr * 64 + m * 32 + (lane & 31), ch));
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) bf[n] = *(const volatile bf16x8*)(sB + swz(wc * 64 + n * 32 + (lane & 31), ch));
+                    for (int n = 0; n < 2; ++n) bf[n] = *(const bf16x8*)(sB + swz(wc * 64 + n * 32 + (lane & 31), ch));
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)

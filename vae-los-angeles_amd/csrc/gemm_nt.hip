@@ -20,7 +20,6 @@
 #include "mmvae_hip.h"
 #include "gemm_src.h"
 #include "gemm_nt_epi.h"
-#include "gemm_ring.h"
 
 namespace mm {
 
@@ -29,17 +28,28 @@ namespace mm {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
-// LDS: main loop 2 x { A [128][128 B] + W [64*WN][128 B] }; the epilogue reuses it as scratch (2-byte tile [128][64*WN] + mask bytes)
+// LDS: main loop 2 x { A [128][128 B] + W [64*WN][128 B] } (64 KiB at WN=2, 96 KiB at WN=4); the epilogue needs none of it
 template <int WN> struct NtLds {
     static constexpr int BUF = (TILE + 64 * WN) * ROW_BYTES;      // one K step of A and W
-    static constexpr int MAIN = 2 * BUF;                          // double buffered
-    static constexpr int SCRATCH = TILE * 64 * WN * 3;            // 48 KiB (WN=2) / 96 KiB (WN=4)
-    static constexpr int STAGE = MAIN > SCRATCH ? MAIN : SCRATCH;
-    static constexpr int TOTAL = STAGE + 4096 + 4 * 64 * WN * 4;   // + BN prologue scale/shift + column-sum scratch
+    static constexpr int STAGE = 2 * BUF;                         // double buffered
+    static constexpr int ECOL = STAGE + 4096 + 4 * 64 * WN * 4;   // + BN prologue scale/shift + column-sum scratch
+    static constexpr int TOTAL = ECOL + 8 * 64 * WN * 4;           // + per-column constants of the epilogue
 };
 
 // WN = 2: 128x128 tile, 4 waves, 2 workgroups per CU.  WN = 4: 128x256 tile, 8 waves, 1 workgroup per CU -- the A tile is
 // fetched once for 256 output columns, which halves the L2->CU operand ingest of the N = 256 / 512 layers.
+#ifdef MM_STAMP
+// Diagnostic build only (make STAMP=1 -> libmmvae_stamp.so, tools/stamp_nt.py): s_memtime stamps at the points of a K step
+// where the wave has drained lgkmcnt anyway, summed per wave and added to mm_stamps[] = {reads + mma0 issue, stage (vmcnt
+// wait + ds_write), barrier wait, fetch + reads + mma1 issue, K steps, waves, whole-kernel cycles summed over waves}.
+__device__ unsigned long long mm_stamps[12];
+#define MM_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define MM_ACC(i, d) st_acc[i] += (d)
+#else
+#define MM_T(x)
+#define MM_ACC(i, d)
+#endif
+
 template <typename CT, typename Src, typename Epi, int WN>
 __global__ __launch_bounds__(128 * WN, 2)
 void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
@@ -51,6 +61,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* aux = (float*)(smem + NtLds<WN>::STAGE);
     float* red = (float*)(smem + NtLds<WN>::STAGE + 4096);
+    float* ecol = (float*)(smem + NtLds<WN>::ECOL);
 
     // XCD-aware tile assignment: linear id L runs on XCD L%8 (round-robin dispatch, speed only).
     const int L = blockIdx.x;
@@ -59,10 +70,15 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     const int rt = (slot / gy) * 8 + (L & 7);
     if (rt >= gx) return;
     const int row0 = rt * TILE, col0 = ct * BN;
+#ifdef MM_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, t_first = 0, t_last = 0;
+    MM_T(t_begin);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
 
+    nt_epilogue_fill_cols<Epi, WN>(ecol, epi, col0, N, tid);       // visible after the first barrier below
     if (Src::NEEDS_AUX) { src.init(aux, tid); __syncthreads(); }
 
     f32x4 acc[4][4];
@@ -86,7 +102,9 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int c = tid + NTH * i, r = c >> 3, ch = c & 7;
-            rb[i].v = *(const decltype(rb[i].v)*)(W + (long)(col0 + r) * ldw + kt * BK + ch * EPC);
+            // the W row that lands in LDS row r: the epilogue's column order inside the wave's 64 columns (gemm_nt_epi.h)
+            const int wr_ = (r & ~63) + EpiCols<sizeof(typename Epi::out_t) == 2>::wrow(r & 63);
+            rb[i].v = *(const decltype(rb[i].v)*)(W + ((unsigned)(col0 + wr_) * (unsigned)ldw + (unsigned)(kt * BK + ch * EPC)));
         }
     };
     auto stage = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt, int buf) {      // registers -> LDS buffer
@@ -105,24 +123,61 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
             *(decltype(rb[i].v)*)(sB + swz(r, ch)) = rb[i].v;
         }
     };
-    auto compute = [&](int buf, int s) {                      // fragment step s (0/1) of an LDS buffer
+    // Fragment registers are double-buffered too: the ds_reads of the NEXT fragment step are issued before the MFMAs of the
+    // current one (tools/ubench_lds_mfma: reads + MFMAs overlap to the MFMA floor when the reads run one block ahead; issued
+    // right before their MFMAs, as the single-set loop did, every fragment step exposed the LDS round trip of all 4 waves).
+    frag f0a[4], f0b[4], f1a[4], f1b[4];
+    auto rd = [&](frag (&af)[4], frag (&bf)[4], int buf, int s) {           // fragment step s (0/1) of an LDS buffer
         const unsigned char* sA = smem + buf * NtLds<WN>::BUF;
         const unsigned char* sB = sA + TILE * ROW_BYTES;
-        frag af[4], bf[4];
         const int ch = s * 4 + (lane >> 4);
 #pragma unroll
         for (int m = 0; m < 4; ++m) af[m] = *(const frag*)(sA + swz(wr * 64 + m * 16 + (lane & 15), ch));
 #pragma unroll
         for (int n = 0; n < 4; ++n) bf[n] = *(const frag*)(sB + swz(wc * 64 + n * 16 + (lane & 15), ch));
+    };
+    auto mma = [&](const frag (&af)[4], const frag (&bf)[4]) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], af[m], bf[n]);
+            for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], bf[n], af[m]);     // swapped: transposed accumulator layout (gemm_nt_epi.h)
+    };
+    // One K step (tile kt in LDS buffer `buf`, its first fragment step already in f0): ONE barrier, in the middle.
+    //   reads (kt, s1) -> f1 | MFMA f0 | tile kt+1: registers -> other LDS buffer | barrier | global fetch of a later tile
+    //   into the registers just staged | reads (kt+1, s0) -> f0 | MFMA f1
+    // Before the barrier every wave has drained its LDS traffic (lgkmcnt(0)), so nobody still reads the buffer the next
+    // step overwrites; after it the freshly staged tile is visible.
+    auto kstep = [&](auto& ra_n, auto& rb_n, int kt, int buf, bool has_next, bool do_fetch, int fetch_kt) {
+        MM_T(t0);
+        rd(f1a, f1b, buf, 1);
+        mma(f0a, f0b);
+        MM_T(t1);
+#ifdef MM_STAMP
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // steady state: the register set about to be staged has landed
+        MM_T(t1b);
+        MM_ACC(5, t1b - t1);
+#endif
+        if (has_next) stage(ra_n, rb_n, kt + 1, buf ^ 1);
+#ifdef MM_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        MM_T(t2);
+        __syncthreads();
+        MM_T(t3);
+        if (do_fetch) fetch(ra_n, rb_n, fetch_kt);
+        if (has_next) rd(f0a, f0b, buf ^ 1, 0);
+        mma(f1a, f1b);
+        MM_T(t4);
+#ifdef MM_STAMP
+        if (st_acc[4] == 0) t_first = t0;
+        t_last = t4;
+#endif
+        MM_ACC(0, t1 - t0); MM_ACC(1, t2 - t1); MM_ACC(2, t3 - t2); MM_ACC(3, t4 - t3); MM_ACC(4, 1);
     };
 
-    // Double-buffered LDS, ONE barrier per K step: while buffer kt&1 is multiplied, tile kt+1 is written into the other
-    // buffer between the two fragment steps and tiles kt+2 / kt+3 are in flight from HBM/L2 in the two register sets.
-    //
+    EpiOperands<Epi> eops;
+    auto pre = [&]() { nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, lane, wr, wc); };     // no-op unless the operands are 16-byte addressable
+
     // hipcc's s_waitcnt insertion is only as precise as the control flow lets it be: a fetch under `if (kt + 3 < nk)`
     // means "maybe 8 fewer loads in flight" at the next stage(), and the wait degrades to vmcnt(0) -- every K step then
     // drains BOTH register sets and the look-ahead is gone (this is what made load phase + MFMA phase add up).  So the
@@ -134,80 +189,56 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         stage(ra0, rb0, 0, 0);
         fetch(ra0, rb0, 2);
         __syncthreads();
+        rd(f0a, f0b, 0, 0);
         int kt = 0;
         for (; kt + 4 < nk; kt += 2) {
-            compute(0, 0);
-            stage(ra1, rb1, kt + 1, 1);
-            compute(0, 1);
-            fetch(ra1, rb1, kt + 3);
-            __syncthreads();
-            compute(1, 0);
-            stage(ra0, rb0, kt + 2, 0);
-            compute(1, 1);
-            fetch(ra0, rb0, kt + 4);
-            __syncthreads();
+            kstep(ra1, rb1, kt, 0, true, true, kt + 3);
+            kstep(ra0, rb0, kt + 1, 1, true, true, kt + 4);
         }
         const bool four = kt + 3 < nk;                        // 3 or 4 K steps left: kt in LDS, kt+1 / kt+2 in flight
-        compute(0, 0);
-        stage(ra1, rb1, kt + 1, 1);
-        compute(0, 1);
-        if (four) fetch(ra1, rb1, kt + 3);
-        __syncthreads();
-        compute(1, 0);
-        stage(ra0, rb0, kt + 2, 0);
-        compute(1, 1);
-        __syncthreads();
-        compute(0, 0);
-        if (four) stage(ra1, rb1, kt + 3, 1);
-        compute(0, 1);
-        __syncthreads();
-        if (four) {
-            compute(1, 0);
-            compute(1, 1);
-            __syncthreads();
-        }
+        kstep(ra1, rb1, kt, 0, true, four, kt + 3);
+        kstep(ra0, rb0, kt + 1, 1, true, false, 0);
+        // epilogue operands: issued before the LAST K step, when both global register sets are dead (any earlier and the
+        // 48 operand registers on top of accumulators + both fragment sets + a live set spilled, 150-300 dwords)
+        if (!four) pre();
+        kstep(ra1, rb1, kt + 2, 0, four, false, 0);
+        if (four) { pre(); kstep(ra1, rb1, kt + 3, 1, false, false, 0); }
     } else {
         fetch(ra0, rb0, 0);
         if (nk > 1) fetch(ra1, rb1, 1);
         stage(ra0, rb0, 0, 0);
         if (nk > 2) fetch(ra0, rb0, 2);
         __syncthreads();
-        compute(0, 0);
-        if (nk > 1) stage(ra1, rb1, 1, 1);
-        compute(0, 1);
-        if (nk > 3) fetch(ra1, rb1, 3);
-        __syncthreads();
-        if (nk > 1) {
-            compute(1, 0);
-            if (nk > 2) stage(ra0, rb0, 2, 0);
-            compute(1, 1);
-            __syncthreads();
-        }
-        if (nk > 2) {
-            compute(0, 0);
-            if (nk > 3) stage(ra1, rb1, 3, 1);
-            compute(0, 1);
-            __syncthreads();
-        }
-        if (nk > 3) {
-            compute(1, 0);
-            compute(1, 1);
-            __syncthreads();
-        }
+        rd(f0a, f0b, 0, 0);
+        if (nk == 1) pre();
+        kstep(ra1, rb1, 0, 0, nk > 1, nk > 3, 3);
+        if (nk > 1) { if (nk == 2) pre(); kstep(ra0, rb0, 1, 1, nk > 2, false, 0); }
+        if (nk > 2) { if (nk == 3) pre(); kstep(ra1, rb1, 2, 0, nk > 3, false, 0); }
+        if (nk > 3) { pre(); kstep(ra1, rb1, 3, 1, false, false, 0); }
     }
 
-    EpiPrefetch pf;                      // epilogue operand tiles (fetched here: the two K-step register sets take the VGPR room)
-    if (!epi.accum()) nt_epilogue_prefetch<CT, Epi, WN>(pf, epi, row0, col0, M, N, tid);
-    nt_epilogue<CT, Epi, WN>(smem, red, acc, epi, pf, row0, col0, M, N, tid, lane, wr, wc);
+    nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+#ifdef MM_STAMP
+    if (tid == 0 && (blockIdx.x & 15) == 3) {        // a sample of waves: same-address atomics from every wave cost more than the kernel
+        MM_T(t_end);
+        for (int i = 0; i < 5; ++i) atomicAdd(&mm_stamps[i], st_acc[i]);
+        atomicAdd(&mm_stamps[5], 1ull);
+        atomicAdd(&mm_stamps[6], t_end - t_begin);
+        atomicAdd(&mm_stamps[7], st_acc[5]);
+        atomicAdd(&mm_stamps[8], t_first - t_begin);
+        atomicAdd(&mm_stamps[9], t_end - t_last);
+    }
+#endif
 }
 
-struct RingSrc { const void* a; long lda; };     // tag: plain bf16 A served by the LDS-ring kernel (gemm_ring.h)
-
-template <typename CT, typename Epi>
-static int launch_nt(const RingSrc& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
-    if constexpr (sizeof(CT) == 2) return launch_nt_ring(src.a, src.lda, W, ldw, M, N, K, epi, st);
-    return MMVAE_ERR_DTYPE;
+#ifdef MM_STAMP
+extern "C" int mmvae_debug_stamps(unsigned long long* out8, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(mm::mm_stamps), 12 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    if (reset) { unsigned long long z[12] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(mm::mm_stamps), z, sizeof(z)); }
+    return (int)e;
 }
+#endif
 
 template <typename CT, typename Src, typename Epi, int WN>
 static int launch_nt_wn(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
@@ -305,7 +336,6 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
     if (a->a_dtype == MMVAE_BF16) {
         if constexpr (sizeof(CT) == 2) {
             if (a->lda % 8 || ((uintptr_t)a->a & 15)) return MMVAE_ERR_ARG;
-            if (ring_ok(a->a, a->lda, a->M)) { RingSrc s{a->a, a->lda}; return dispatch_epi<CT>(a, s, st); }
             SrcPlain<CT, bf16, 8> s{(const bf16*)a->a, a->lda, a->M, a->K};
             return dispatch_epi<CT>(a, s, st);
         }
@@ -336,6 +366,10 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     if (!a || !a->a || !a->w || (!a->c && !(a->epilogue == MMVAE_EPI_BN_BWD && a->bn_phase == 0))) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
     if (a->ldw % 64 || ((uintptr_t)a->w & 15)) return MMVAE_ERR_ARG;
+    // the kernels address A, W and the prologue mask with 32-bit byte offsets from a scalar base
+    const long lim = 1L << 32;
+    if ((long)a->M * a->lda * (a->a_dtype == MMVAE_BF16 ? 2 : 4) >= lim || ((long)a->N + 256) * a->ldw * 4 >= lim) return MMVAE_ERR_ARG;
+    if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (a->prec == MMVAE_PREC_BF16) return mm::dispatch_src<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::dispatch_src<float>(a, st);

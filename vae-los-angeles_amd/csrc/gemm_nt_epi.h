@@ -1,6 +1,18 @@
-// Epilogues of the NT GEMM kernels (register-staged kernel in gemm_nt.hip, LDS-ring kernel in
-// gemm_ring.hip): what happens to the f32 accumulators of a 128x128 tile owned by 4 waves (2x2,
-// 64x64 each, 4x4 MFMA 16x16 tiles per wave).
+// Epilogues of the NT GEMM kernel (gemm_nt.hip): what happens to the f32 accumulators of a 128 x (64*WN) tile owned by
+// 2*WN waves, 64x64 each, 4x4 MFMA 16x16 tiles per wave.
+//
+// The kernel multiplies with the operands SWAPPED (W fragment as MFMA "A", activation fragment as "B"), so a 16x16
+// accumulator tile comes out transposed: lane (li = lane & 15, lg = lane >> 4) holds, for tile (m, n),
+//     row  = 64*wr + 16*m + li                      (one activation row per lane)
+//     cols = 64*wc + wrow(16*n + 4*lg + j)          (j = 0..3: four consecutive columns)
+// where wrow() is the order in which the W rows of the wave's 64 columns were put into the MFMA tiles (EpiCols below: the
+// kernel applies it to the W row it FETCHES for each LDS row, which costs nothing).  For 4-byte outputs wrow is the
+// identity: a lane's 4 columns are 16 bytes and the 4 lane groups complete 64 contiguous bytes of the row.  For 2-byte
+// outputs tiles (2g, 2g+1) are interleaved so that a lane owns 8 consecutive columns (16 bytes) and the 4 lane groups
+// again complete 64 contiguous bytes (8-byte pieces measured 35 % slower on the store-bound layers).
+// Every epilogue access is a per-lane 16-byte vector: operands are read and results stored straight from/to global
+// memory with no LDS transpose, no barrier and no idle waves.  The LDS-staged form this replaces cost as many cycles per
+// tile as an 8-step main loop (tools/stamp_nt.py: 12-14 k cycles per wave, 64 ds_write_b16 per lane).
 #pragma once
 #include "common.h"
 
@@ -20,14 +32,20 @@ struct EpiStore {               // C = act(acc + bias) (+ C) ; stats = (sum C, s
     const OT* H; long ldh; const uint8_t* mask; long ldm;     // unused
     double* stat1; double* stat2;
     struct Col { float b; };
+    static constexpr int NCOL = 1;            // per-column constants kept in LDS (BN floats each)
     __device__ __forceinline__ bool stores() const { return true; }
     __device__ __forceinline__ bool accum() const { return accumulate != 0; }
     bool accumulate_requested() const { return accumulate != 0; }
-    __device__ __forceinline__ Col col(int c, int N) const { return Col{(bias && c < N) ? bias[c] : 0.f}; }
+    __device__ __forceinline__ void fill(float* e, int BN, int cl, int c, int N) const { e[cl] = (bias && c < N) ? bias[c] : 0.f; }
+    __device__ __forceinline__ Col col(const float* e, int BN, int cl) const { return Col{e[cl]}; }
+    // ACT >= 0: the activation is known at compile time (the epilogue dispatches on it once per tile); ACT < 0: run time
+    __device__ __forceinline__ int act_code() const { return act; }
+    template <int ACT>
     __device__ __forceinline__ float compute(float v, float, unsigned, const Col& cc, bool count, float& s1, float& s2) const {
         v += cc.b;
-        if (act == 1) v = fmaxf(v, 0.f);
-        else if (act == 2) v = 1.f / (1.f + expf(-v));
+        const int a = ACT < 0 ? act : ACT;
+        if (a == 1) v = fmaxf(v, 0.f);
+        else if (a == 2) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));       // v_exp_f32 / v_rcp_f32: ~1 ulp each, no IEEE-division sequence
         const float r = to_f32(from_f32<OT>(v));
         if (STATS && count) { s1 += r; s2 += r * r; }
         return r;
@@ -42,10 +60,14 @@ struct EpiReluMask {            // dH = (H > 0) ? acc : 0
     OT* C; long ldc; const HT* H; long ldh; const uint8_t* mask; long ldm;
     double* stat1; double* stat2;
     struct Col {};
+    static constexpr int NCOL = 0;
     __device__ __forceinline__ bool stores() const { return true; }
     __device__ __forceinline__ bool accum() const { return false; }
     bool accumulate_requested() const { return false; }
-    __device__ __forceinline__ Col col(int, int) const { return Col{}; }
+    __device__ __forceinline__ void fill(float*, int, int, int, int) const {}
+    __device__ __forceinline__ Col col(const float*, int, int) const { return Col{}; }
+    __device__ __forceinline__ int act_code() const { return 0; }
+    template <int ACT>
     __device__ __forceinline__ float compute(float v, float h, unsigned, const Col&, bool, float&, float&) const {
         return h > 0.f ? v : 0.f;
     }
@@ -69,14 +91,17 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     __device__ __forceinline__ bool stores() const { return phase != 0; }
     __device__ __forceinline__ bool accum() const { return false; }
     bool accumulate_requested() const { return false; }
-    __device__ __forceinline__ Col col(int c, int N) const {
-        Col k{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (c < N) {
-            k.sc = scale[c]; k.sh = shift[c]; k.mu = mean[c]; k.rs = rstd[c];
-            if (phase == 1) { k.c0 = coef[c]; k.c1 = coef[N + c]; k.c2 = coef[2 * N + c]; }
-        }
-        return k;
+    static constexpr int NCOL = 7;
+    __device__ __forceinline__ void fill(float* e, int BN, int cl, int c, int N) const {
+        const bool ok = c < N, p1 = ok && phase == 1;
+        e[cl] = ok ? scale[c] : 0.f; e[BN + cl] = ok ? shift[c] : 0.f; e[2 * BN + cl] = ok ? mean[c] : 0.f; e[3 * BN + cl] = ok ? rstd[c] : 0.f;
+        e[4 * BN + cl] = p1 ? coef[c] : 0.f; e[5 * BN + cl] = p1 ? coef[N + c] : 0.f; e[6 * BN + cl] = p1 ? coef[2 * N + c] : 0.f;
     }
+    __device__ __forceinline__ Col col(const float* e, int BN, int cl) const {
+        return Col{e[cl], e[BN + cl], e[2 * BN + cl], e[3 * BN + cl], e[4 * BN + cl], e[5 * BN + cl], e[6 * BN + cl]};
+    }
+    __device__ __forceinline__ int act_code() const { return 0; }
+    template <int ACT>
     __device__ __forceinline__ float compute(float v, float y, unsigned mb, const Col& cc, bool count, float& s1, float& s2) const {
         const float keep = mask ? (mb ? inv_keep : 0.f) : 1.f;
         const float d = (y * cc.sc + cc.sh > 0.f) ? v * keep : 0.f;
@@ -86,151 +111,233 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     }
 };
 
-// Epilogue operand tiles (ReLU input / pre-BN output, keep mask) fetched into REGISTERS; issued before the main loop
-// so that their HBM latency is hidden under the contraction instead of being exposed between main loop and stores.
-struct EpiPrefetch { f32x4 h[8]; f32x4 m[4]; };
+// Column order of a wave's 64 output columns inside its 4 MFMA n-tiles.
+template <bool PAIR> struct EpiCols {
+    static constexpr int G = PAIR ? 8 : 4;            // consecutive columns a lane owns per group
+    static constexpr int NG = 16 / G;                 // groups per lane (x 4 rows m)
+    // W row (relative to the wave's 64) that goes to LDS row x = 16*n + i of the wave's W block
+    static __device__ __forceinline__ int wrow(int x) {
+        if constexpr (!PAIR) return x;
+        const int n = x >> 4, i = x & 15;
+        return 32 * (n >> 1) + 8 * (i >> 2) + 4 * (n & 1) + (i & 3);
+    }
+    // first column (relative to the wave's 64) of group g for lane group lg; element e of the group is accumulator
+    // (n, j) = (PAIR ? 2g + (e >> 2) : g, e & 3)
+    static __device__ __forceinline__ int base(int g, int lg) { return PAIR ? 32 * g + 8 * lg : 16 * g + 4 * lg; }
+    static constexpr __device__ __forceinline__ int tile(int g, int e) { return PAIR ? 2 * g + (e >> 2) : g; }
+};
 
-// WN = waves along N: the tile is 128 x (64*WN), owned by 2*WN waves (128*WN threads).  The per-thread chunk counts of the
-// cooperative tile loads/stores below are independent of WN (8 x 16 B of a 2-byte tile, 4 x 16 B of the mask).
-template <typename CT, typename Epi, int WN = 2>
-__device__ __forceinline__ void nt_epilogue_prefetch(EpiPrefetch& pf, const Epi& epi, int row0, int col0, int M, int N, int tid) {
+// Epilogue operands (ReLU input / pre-BN output, keep mask) in the accumulator's own layout, fetched into registers a
+// couple of K steps before the main loop ends so that their HBM latency is covered by the last MFMAs.
+template <typename Epi>
+struct EpiOperands {
     typedef typename Epi::h_t HT;
-    constexpr int BN = 64 * WN, NTH = 128 * WN;
-    if constexpr (sizeof(CT) == 2 && Epi::NEED >= 1 && sizeof(HT) == 2) {
+    typedef EpiCols<sizeof(typename Epi::out_t) == 2> EC;
+    static constexpr int HD = EC::G * (int)sizeof(HT) / 4;        // dwords of H per group
+    static constexpr int MD = EC::G / 4;                           // dwords of mask bytes per group
+    static_assert(Epi::NEED == 0 || HD == 4, "epilogue operand groups are 16-byte vectors (H and output of the same width)");
+    uint32_t h[4 * EC::NG][HD];
+    uint32_t mk[4 * EC::NG][MD];
+};
+
+template <typename Epi> __device__ __forceinline__ bool epi_h_vec(const Epi& epi) {
+    return Epi::NEED >= 1 && (epi.ldh * sizeof(typename Epi::h_t)) % 16 == 0 && ((uintptr_t)epi.H & 15) == 0;
+}
+template <typename Epi> __device__ __forceinline__ bool epi_m_vec(const Epi& epi) {
+    return Epi::NEED >= 2 && epi.mask != nullptr && epi.ldm % 8 == 0 && ((uintptr_t)epi.mask & 7) == 0;
+}
+
+// Branch-free (clamped addresses): these loads are issued between K steps, where a conditional load would cost the
+// counted vmcnt waits of the remaining stage() calls (see gemm_src.h).  wr/wc: wave row/column inside the tile.
+// HALF 0: the groups the epilogue consumes first (issued before the last K step); HALF 1: the rest (issued when the
+// epilogue starts, covered by the work on the first half) -- all 48 operand registers at once did not fit next to the
+// accumulators and both fragment sets, and hipcc spilled the values it had just loaded.
+template <typename Epi, int HALF>
+__device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, const Epi& epi, int row0, int col0, int M, int lane, int wr, int wc) {
+    typedef EpiOperands<Epi> EO;
+    typedef typename EO::EC EC;
+    const int li = lane & 15, lg = lane >> 4;
+    if constexpr (Epi::NEED >= 1) {
+        if (epi_h_vec(epi)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = tid + NTH * i, r = c / (BN / 8), ch = c % (BN / 8);
-            const int gr = row0 + r, gc = col0 + ch * 8;
-            pf.h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gr < M && gc < N) pf.h[i] = *(const f32x4*)(epi.H + (long)gr * epi.ldh + gc);     // rows padded to 8 elements
+            for (int g = HALF * EC::NG / 2; g < (HALF + 1) * EC::NG / 2; ++g) {      // g-major: the order in which the epilogue consumes them
+                const int c = col0 + wc * 64 + EC::base(g, lg);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldh;
+                    const uint4 t = *(const uint4*)(epi.H + ro + (c + EC::G <= epi.ldh ? c : 0));
+                    ops.h[m * EC::NG + g][0] = t.x; ops.h[m * EC::NG + g][1] = t.y; ops.h[m * EC::NG + g][2] = t.z; ops.h[m * EC::NG + g][3] = t.w;
+                }
+            }
         }
-        if (Epi::NEED >= 2 && epi.mask != nullptr) {
+    }
+    if constexpr (Epi::NEED >= 2) {
+        if (epi_m_vec(epi)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = tid + NTH * i, r = c / (BN / 16), ch = c % (BN / 16);
-                const int gr = row0 + r, gc = col0 + ch * 16;
-                pf.m[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gr < M && gc < N) pf.m[i] = *(const f32x4*)(epi.mask + (long)gr * epi.ldm + gc);   // N % 16 == 0 checked on the host
+            for (int g = HALF * EC::NG / 2; g < (HALF + 1) * EC::NG / 2; ++g) {
+                const int c = col0 + wc * 64 + EC::base(g, lg);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldm;
+                    const uint8_t* q = epi.mask + ro + (c + EC::G <= epi.ldm ? c : 0);
+                    if constexpr (EO::MD == 2) { const uint2 t = *(const uint2*)q; ops.mk[m * EC::NG + g][0] = t.x; ops.mk[m * EC::NG + g][1] = t.y; }
+                    else ops.mk[m * EC::NG + g][0] = *(const uint32_t*)q;
+                }
             }
         }
     }
 }
 
-// smem: >= 24 KiB * WN scratch (free to overwrite), red: 1 KiB * WN.  wr/wc: wave row/column inside the tile.
-template <typename CT, typename Epi, int WN = 2>
-__device__ __forceinline__ void nt_epilogue(unsigned char* smem, float* red, f32x4 (&acc)[4][4], const Epi& epi, const EpiPrefetch& pf,
-                                            int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
+// Per-column constants of the epilogue (bias; BatchNorm scale/shift/mean/rstd/coefficients) go to LDS once per tile, at
+// kernel start (the kernel's first barrier orders it): held in registers they cost up to 56 VGPRs of an epilogue that
+// already carries 64 accumulators and 48 prefetched operand registers, and spilled.  ecol: NCOL * 64*WN floats.
+template <typename Epi, int WN>
+__device__ __forceinline__ void nt_epilogue_fill_cols(float* ecol, const Epi& epi, int col0, int N, int tid) {
+    constexpr int BN = 64 * WN;
+    if (Epi::NCOL > 0 && tid < BN) epi.fill(ecol, BN, tid, col0 + tid, N);
+}
+
+// The per-element work of the epilogue, specialised on what is uniform over the tile so that the 128 elements of a lane
+// run without scalar branches: ACT (activation, -1 = run time), ACCUM (C += ...), VEC (operands prefetched as vectors;
+// otherwise per-element guarded loads: odd leading dimensions, f32 precision mode corner cases).  The generic form cost
+// ~5000 instructions per lane (8-10 k cycles per tile, as much as 5 K steps); this one ~600.
+template <typename Epi, int ACT, bool ACCUM, bool VEC>
+__device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)[4][4], const Epi& epi, const EpiOperands<Epi>& ops,
+                                                 float (&s1)[16], float (&s2)[16], int BN, int row0, int col0, int M, int N, int lane, int wr, int wc)
 {
-    constexpr int BN = 64 * WN, NTH = 128 * WN, RB = BN * 2;      // RB: row bytes of a staged 2-byte tile
     typedef typename Epi::out_t OT;
     typedef typename Epi::h_t HT;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef EpiOperands<Epi> EO;
+    typedef typename EO::EC EC;
+    constexpr int G = EC::G, NG = EC::NG;
+    constexpr int EPCO = 16 / (int)sizeof(OT);
     const int li = lane & 15, lg = lane >> 4;
-    // Staged form: 2-byte activation tiles go through LDS so that every global access of the epilogue is a
-    // full-line 16-byte access.  The f32 precision mode (parity tool) and accumulate-into-C use the direct form.
-    constexpr bool CAN_STAGE = sizeof(CT) == 2 && (Epi::NEED == 0 || sizeof(HT) == 2);
-    if (CAN_STAGE && !epi.accum()) {
-        unsigned char* sT = smem;                               // [128][128] of a 2-byte type, or [64][128] f32
-        unsigned char* sM = smem + TILE * RB;                    // [128][BN] mask bytes
-        if (Epi::NEED >= 1) {                                   // operand tiles: registers (prefetched) -> LDS
+    const int n_store = (int)min((long)((N + EPCO - 1) / EPCO * EPCO), epi.ldc);      // pad columns of internal buffers get zeros
+    const bool c16 = (epi.ldc * sizeof(OT)) % 16 == 0 && ((uintptr_t)epi.C & 15) == 0;     // whole-group vector stores
+    const bool c8 = (epi.ldc * sizeof(OT)) % 8 == 0 && ((uintptr_t)epi.C & 7) == 0;
+    const bool has_mask = Epi::NEED >= 2 && epi.mask != nullptr;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = tid + NTH * i, r = c / (BN / 8), ch = c % (BN / 8);
-                *(f32x4*)(sT + r * RB + ch * 16) = pf.h[i];
-            }
-            if (Epi::NEED >= 2 && epi.mask != nullptr) {
+    for (int g = 0; g < NG; ++g) {
+        const int cw = wc * 64 + EC::base(g, lg), c0 = col0 + cw;
+        typename Epi::Col cc[G];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = tid + NTH * i, r = c / (BN / 16), ch = c % (BN / 16);
-                    *(f32x4*)(sM + r * BN + ch * 16) = pf.m[i];
+        for (int e = 0; e < G; ++e) cc[e] = epi.col(ecol, BN, cw + e);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = row0 + wr * 64 + m * 16 + li;
+            const bool rok = row < M;
+            float hv[G]; unsigned mb[G]; float o[G];
+#pragma unroll
+            for (int e = 0; e < G; ++e) { hv[e] = 0.f; mb[e] = 1u; o[e] = 0.f; }
+            if constexpr (Epi::NEED >= 1) {
+                if constexpr (VEC) {
+#pragma unroll
+                    for (int e = 0; e < G; ++e) {
+                        if constexpr (sizeof(HT) == 2) {
+                            const uint32_t w = ops.h[m * NG + g][e >> 1];
+                            hv[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                        } else hv[e] = __uint_as_float(ops.h[m * NG + g][e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < G; ++e) if (rok && c0 + e < N) hv[e] = to_f32(epi.H[(long)row * epi.ldh + c0 + e]);
                 }
             }
-            __syncthreads();
-        }
-        constexpr int HALVES = sizeof(OT) == 2 ? 1 : 2;         // f32 outputs are staged 64 rows at a time
+            if constexpr (Epi::NEED >= 2) {
+                if constexpr (VEC) {
+                    if (has_mask) {
 #pragma unroll
-        for (int hf = 0; hf < HALVES; ++hf) {
-            if (HALVES == 1 || wr == hf) {
+                        for (int e = 0; e < G; ++e) mb[e] = (ops.mk[m * NG + g][e >> 2] >> (8 * (e & 3))) & 0xffu;
+                    }
+                } else if (has_mask) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int cl = wc * 64 + n * 16 + li, c = col0 + cl;
-                    typename Epi::Col cc = epi.col(c, N);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int rl = wr * 64 + m * 16 + lg * 4 + j;
-                            const bool ok = (row0 + rl < M) && (c < N);
-                            float hv = 0.f; unsigned mb = 1;
-                            if (Epi::NEED >= 1) hv = to_f32(*(const HT*)(sT + rl * RB + cl * 2));
-                            if (Epi::NEED >= 2) mb = sM[rl * BN + cl];
-                            float o = epi.compute(acc[m][n][j], hv, mb, cc, ok, s1[n], s2[n]);
-                            if (c >= N) o = 0.f;
-                            const int rs = HALVES == 1 ? rl : rl - hf * 64;
-                            *(OT*)(sT + (rs * BN + cl) * (int)sizeof(OT)) = from_f32<OT>(o);
-                        }
+                    for (int e = 0; e < G; ++e) if (rok && c0 + e < N) mb[e] = epi.mask[(long)row * epi.ldm + c0 + e];
                 }
             }
-            if (epi.stores()) {
-                __syncthreads();
-                constexpr int CPR = BN * (int)sizeof(OT) / 16, EPCO = 16 / (int)sizeof(OT);
-                const bool v16 = ((epi.ldc * sizeof(OT)) % 16 == 0) && (((uintptr_t)epi.C & 15) == 0);
-                const bool v8 = ((epi.ldc * sizeof(OT)) % 8 == 0) && (((uintptr_t)epi.C & 7) == 0);
-                const int n_store = (int)min((long)((N + EPCO - 1) / EPCO * EPCO), epi.ldc);   // pad columns of internal buffers get zeros
+            OT* gp = epi.C + (long)row * epi.ldc + c0;
+            if constexpr (ACCUM) {                               // C += ...: read the old values first
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = tid + NTH * i, r = c / CPR, ch = c % CPR;
-                    const int gr = row0 + hf * (TILE / HALVES) + r, gc = col0 + ch * EPCO;
-                    if (gr >= M || gc >= n_store) continue;
-                    const unsigned char* sp = sT + r * (BN * (int)sizeof(OT)) + ch * 16;
-                    OT* gp = epi.C + (long)gr * epi.ldc + gc;
-                    if (gc + EPCO <= n_store && v16) *(f32x4*)gp = *(const f32x4*)sp;
-                    else if (gc + EPCO <= n_store && v8) { ((f32x2*)gp)[0] = ((const f32x2*)sp)[0]; ((f32x2*)gp)[1] = ((const f32x2*)sp)[1]; }
+                for (int e = 0; e < G; ++e) if (rok && c0 + e < N) o[e] = to_f32(gp[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int n = EC::tile(g, e), j = e & 3;
+                const bool ok = rok && (c0 + e < N);
+                float v = epi.template compute<ACT>(acc[m][n][j], hv[e], mb[e], cc[e], ok, s1[n * 4 + j], s2[n * 4 + j]);
+                if constexpr (ACCUM) v += o[e];
+                o[e] = (c0 + e < N) ? v : 0.f;
+            }
+            if (epi.stores() && rok && c0 < n_store) {
+                const bool whole = c0 + G <= n_store;
+                if constexpr (sizeof(OT) == 2) {
+                    if (whole && c16) {
+                        const bf16x8 t = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3], (bf16)o[4], (bf16)o[5], (bf16)o[6], (bf16)o[7]};
+                        *(bf16x8*)gp = t;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < G; ++e) if (c0 + e < n_store) gp[e] = from_f32<OT>(o[e]);
+                    }
+                } else {
+                    if (whole && c16) *(f32x4*)gp = f32x4{o[0], o[1], o[2], o[3]};
+                    else if (whole && c8) { ((f32x2*)gp)[0] = f32x2{o[0], o[1]}; ((f32x2*)gp)[1] = f32x2{o[2], o[3]}; }
                     else {
 #pragma unroll
-                        for (int e = 0; e < EPCO; ++e) if (gc + e < n_store) gp[e] = ((const OT*)sp)[e];
+                        for (int e = 0; e < G; ++e) if (c0 + e < n_store) gp[e] = from_f32<OT>(o[e]);
                     }
                 }
-                if (HALVES == 2 && hf == 0) __syncthreads();
-            }
-        }
-    } else {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int c = col0 + wc * 64 + n * 16 + li;
-            if (c < N) {
-                typename Epi::Col cc = epi.col(c, N);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = row0 + wr * 64 + m * 16 + lg * 4 + j;
-                        if (r < M) {
-                            float hv = 0.f; unsigned mb = 1;
-                            if (Epi::NEED >= 1) hv = to_f32(epi.H[(long)r * epi.ldh + c]);
-                            if (Epi::NEED >= 2 && epi.mask) mb = epi.mask[(long)r * epi.ldm + c];
-                            float o = epi.compute(acc[m][n][j], hv, mb, cc, true, s1[n], s2[n]);
-                            if (epi.stores()) {
-                                OT* q = epi.C + (long)r * epi.ldc + c;
-                                if (epi.accum()) o += to_f32(*q);
-                                *q = from_f32<OT>(o);
-                            }
-                        }
-                    }
             }
         }
     }
-    if (Epi::STATS && (epi.stat1 != nullptr || epi.stat2 != nullptr)) {
-        __syncthreads();                                        // red[] is separate from the staging area, but order the reuse
+}
+
+// red: 1 KiB * WN of LDS (column partial sums of the 2 wave rows), only touched by STATS epilogues.
+template <typename CT, typename Epi, int WN = 2>
+__device__ __forceinline__ void nt_epilogue(float* red, const float* ecol, f32x4 (&acc)[4][4], const Epi& epi, EpiOperands<Epi>& ops,
+                                            int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
+{
+    constexpr int BN = 64 * WN;
+    typedef EpiOperands<Epi> EO;
+    typedef typename EO::EC EC;
+    const int li = lane & 15, lg = lane >> 4;
+    float s1[16], s2[16];                                       // per accumulator (n, j): index 4n + j
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            s1[n] += __shfl_xor(s1[n], 16, 64); s1[n] += __shfl_xor(s1[n], 32, 64);
-            s2[n] += __shfl_xor(s2[n], 16, 64); s2[n] += __shfl_xor(s2[n], 32, 64);
-            if (lane < 16) {
-                red[(wr * 2 + 0) * BN + wc * 64 + n * 16 + lane] = s1[n];
-                red[(wr * 2 + 1) * BN + wc * 64 + n * 16 + lane] = s2[n];
+    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    // operands arrive as prefetched vectors unless a leading dimension / base address rules 16-byte accesses out
+    const bool vec = (Epi::NEED < 1 || epi_h_vec(epi)) && (Epi::NEED < 2 || epi.mask == nullptr || epi_m_vec(epi));
+    if (epi.accum()) {
+        nt_epilogue_body<Epi, -1, true, false>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+    } else if (!vec) {
+        nt_epilogue_body<Epi, -1, false, false>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+    } else {
+        nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, lane, wr, wc);
+        const int a = epi.act_code();
+        if (a == 0) nt_epilogue_body<Epi, 0, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+        else if (a == 1) nt_epilogue_body<Epi, 1, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+        else nt_epilogue_body<Epi, 2, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+    }
+    if (Epi::STATS && (epi.stat1 != nullptr || epi.stat2 != nullptr)) {
+        // Column sums: 32 partials per lane (s1 / s2 of 16 accumulator columns) over the 16 lanes li of a lane group.
+        // Reduce-scatter butterfly (xor 8, 4, 2, 1: 16 + 8 + 4 + 2 shuffles): each step a lane keeps the half of its
+        // values selected by one bit of li and adds the partner's copy of that half.  v index = which*16 + n*4 + j, so lane
+        // li ends up with which = li >> 3, n = (li >> 1) & 3, j = 2*(li & 1) + {0, 1} (two adjacent columns in either order).
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = s1[i]; v[16 + i] = s2[i]; }
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int bit = 8 >> step, half = 16 >> step;
+            const bool up = (li & bit) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float keep = up ? v[i + half] : v[i];
+                const float send = up ? v[i] : v[i + half];
+                v[i] = keep + __shfl_xor(send, bit, 64);
             }
         }
+        const int which = li >> 3;
+        const int cl = wc * 64 + EC::wrow(((li >> 1) & 3) * 16 + lg * 4 + 2 * (li & 1));
+        red[(wr * 2 + which) * BN + cl] = v[0];
+        red[(wr * 2 + which) * BN + cl + 1] = v[1];
         __syncthreads();
         if (tid < BN && col0 + tid < N) {
             if (epi.stat1) unsafeAtomicAdd(epi.stat1 + col0 + tid, (double)(red[0 * BN + tid] + red[2 * BN + tid]));

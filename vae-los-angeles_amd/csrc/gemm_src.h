@@ -24,9 +24,9 @@ template <int EPC> struct RawVec<float, EPC> {
 // makes hipcc wrap each load in an exec-masked block whose else-side writes the same VGPRs, which forces an
 // s_waitcnt vmcnt(0) after every load and serialises the whole K-step prefetch (seen in the gfx950 ISA).
 template <int EPC, int VEC>
-__device__ __forceinline__ void load_chunk_f32(RawVec<float, EPC>& r, const float* row_ptr, int k, int K) {
+__device__ __forceinline__ void load_chunk_f32(RawVec<float, EPC>& r, const float* p, unsigned row_off, int k, int K) {
 #pragma unroll
-    for (int j = 0; j < EPC; j += VEC) VLoad<float, VEC>::ld(row_ptr + min(k + j, K - VEC), &r.v[j]);     // K % VEC == 0, K >= VEC
+    for (int j = 0; j < EPC; j += VEC) VLoad<float, VEC>::ld(p + (row_off + (unsigned)min(k + j, K - VEC)), &r.v[j]);     // K % VEC == 0, K >= VEC
 }
 
 // Plain A[M][K] (element type AT, row stride lda, vectors of VEC elements; K % VEC == 0).
@@ -38,11 +38,13 @@ struct SrcPlain {
     typedef RawVec<AT, EPC> Raw;
     __device__ __forceinline__ void init(float*, int) const {}
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {
-        const AT* q = p + (long)min(row, M - 1) * lda;
+        // 32-bit element offsets (the entry points reject operands of 4 GiB or more): the loads take the
+        // scalar-base + 32-bit-VGPR-offset form, one address VGPR per load instead of a 64-bit pair
+        const unsigned ro = (unsigned)min(row, M - 1) * (unsigned)lda;
         if constexpr (sizeof(AT) == 2) {
-            r.v = *(const bf16x8*)(q + min(k, ((K + 7) & ~7) - 8));      // internal buffers: rows padded to 8 elements
+            r.v = *(const bf16x8*)(p + (ro + (unsigned)min(k, ((K + 7) & ~7) - 8)));      // internal buffers: rows padded to 8 elements
         } else {
-            load_chunk_f32<EPC, VEC>(r, q, k, K);
+            load_chunk_f32<EPC, VEC>(r, p, ro, k, K);
         }
     }
     __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float*) const {
@@ -77,14 +79,14 @@ struct SrcBnReluDrop {
     }
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {        // K % EPC == 0 (hidden widths)
         const int rc = min(row, M - 1), kc = min(k, K - EPC);
-        const CT* q = y + (long)rc * ldy + kc;
+        const CT* q = y + ((unsigned)rc * (unsigned)ldy + (unsigned)kc);
         if constexpr (sizeof(CT) == 2) {
             r.y.v = *(const bf16x8*)q;
         } else {
             f32x4 t = *(const f32x4*)q; r.y.v[0] = t[0]; r.y.v[1] = t[1]; r.y.v[2] = t[2]; r.y.v[3] = t[3];
         }
         if (mask != nullptr) {                           // kernel-argument uniform: a scalar branch
-            const uint32_t* mp = (const uint32_t*)(mask + (long)rc * ldm + kc);
+            const uint32_t* mp = (const uint32_t*)(mask + ((unsigned)rc * (unsigned)ldm + (unsigned)kc));
 #pragma unroll
             for (int i = 0; i < EPC / 4; ++i) r.m[i] = mp[i];
         } else {

@@ -415,6 +415,10 @@ static int tn_dispatch_p(const mmvae_gemm_tn_args* a, hipStream_t st) {
 extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (!a || !a->p || !a->q || !a->dw) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
+    // the operand sources address P, Q and the prologue mask with 32-bit byte offsets from a scalar base
+    const long lim = 1L << 32;
+    if ((long)a->M * a->ldp * (a->p_dtype == MMVAE_BF16 ? 2 : 4) >= lim || (long)a->M * a->ldq * (a->q_dtype == MMVAE_BF16 ? 2 : 4) >= lim) return MMVAE_ERR_ARG;
+    if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (a->prec == MMVAE_PREC_BF16) {
         if (a->p_dtype == MMVAE_BF16 && a->q_dtype == MMVAE_BF16 && a->q_prologue == MMVAE_PRO_NONE &&
