@@ -11,13 +11,16 @@
 //     row-major tile ([32 m][128 cols], 64-byte chunks swizzled by row parity) suffices.
 // Q may carry the BN-normalise + ReLU + Dropout prologue (it is then the previous layer's
 // pre-BN output), so post-activation tensors are never materialised.
+// Pipeline: two global register sets (one for f32 sources), double-buffered LDS with one barrier per
+// batch step, steady-state loop without conditional fetches (see gemm_nt.hip for why).  tools/stamp_tn.py
+// shows where a step goes: the global loads are never waited for; the registers -> LDS stage and the
+// transpose reads are what the MFMAs wait on.
 // The batch is split over `nsplit` workgroups per output tile; partial tiles are combined with
 // f32 global atomics (memory-side adds on gfx950; dW must be zeroed by the caller).  All tiles of
 // one batch split run on one XCD so that P / Q rows are fetched from HBM once and shared in L2.
 #include "common.h"
 #include "mmvae_hip.h"
 #include "gemm_src.h"
-#include "gemm_ring.h"
 
 namespace mm {
 
@@ -59,6 +62,15 @@ __device__ __forceinline__ f32x4 tn_frag(const unsigned char* tile, int colbase,
     return v;
 }
 
+#ifdef MM_STAMP
+// Diagnostic build only (make STAMP=1, tools/stamp_tn.py): cycles per batch step of {fragment step 0, stage, fragment step 1
+// + fetch issue, barrier}, steps, waves, whole-kernel cycles, cycles before the loop, cycles after it.
+__device__ unsigned long long mm_stamps_tn[12];
+#define MT_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define MT_T(x)
+#endif
+
 template <typename CT, typename PSrc, typename QSrc>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
@@ -67,10 +79,9 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     typedef TnGeom<CT> G;
     constexpr int EPC = Mma<CT>::EPC;
     typedef typename Mma<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::MT * G::ROWB + 4096];
-    unsigned char* sP = smem;
-    unsigned char* sQ = smem + G::MT * G::ROWB;
-    float* aux = (float*)(smem + 2 * G::MT * G::ROWB);
+    constexpr int BUF = 2 * G::MT * G::ROWB;                 // one batch step: P tile + Q tile (32 KiB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
+    float* aux = (float*)(smem + 2 * BUF);
 
     const int L = blockIdx.x, slot = L >> 3;
     const int tile = slot % ntiles;
@@ -95,26 +106,31 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool do_bias = (db != nullptr) && tk == 0 && wc == 0;     // wave-uniform
 
-    typename PSrc::Raw rp[4];
-    typename QSrc::Raw rq[4];
+    // Same pipeline as the NT kernel (gemm_nt.hip): two global register sets, double-buffered LDS with ONE barrier per
+    // batch step, fragment registers double-buffered so the transpose reads run one fragment step ahead of the MFMAs,
+    // and a steady-state loop without conditional fetches so that hipcc can count its vmcnt waits.
+    typename PSrc::Raw rp0[4], rp1[4];
+    typename QSrc::Raw rq0[4], rq1[4];
     const int nt = (m_end - m_begin + G::MT - 1) / G::MT;
 
-    auto fetch = [&](int t) {
+    auto fetch = [&](typename PSrc::Raw (&rp)[4], typename QSrc::Raw (&rq)[4], int t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int c = tid + NTHREADS * i, r = c / G::CPR, ch = c % G::CPR;
             int m = m_begin + t * G::MT + r;
-            if (m >= m_end) m = M;            // rows past this split read as zeros
+            m = m >= m_end ? M : m;           // rows past this split read as zeros (finish() zeroes rows >= M)
             ps.fetch(rp[i], m, n0 + ch * EPC);
             qs.fetch(rq[i], m, k0 + ch * EPC);
         }
     };
-    auto stage = [&](int t) {
+    auto stage = [&](typename PSrc::Raw (&rp)[4], typename QSrc::Raw (&rq)[4], int t, int buf) {
+        unsigned char* sP = smem + buf * BUF;
+        unsigned char* sQ = sP + G::MT * G::ROWB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int c = tid + NTHREADS * i, r = c / G::CPR, ch = c % G::CPR;
             int m = m_begin + t * G::MT + r;
-            if (m >= m_end) m = M;
+            m = m >= m_end ? M : m;
             Chunk<CT> o;
             ps.finish(rp[i], m, n0 + ch * EPC, o, aux);
             *(decltype(o.v)*)(sP + G::chunk_off(r, ch)) = o.v;
@@ -122,31 +138,99 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             *(decltype(o.v)*)(sQ + G::chunk_off(r, ch)) = o.v;
         }
     };
-
-    fetch(0);
-    for (int t = 0; t < nt; ++t) {
-        stage(t);
-        __syncthreads();
-        if (t + 1 < nt) fetch(t + 1);
+    // ONE fragment set here (the NT kernel double-buffers it): the transpose reads need two LDS addresses per fragment and
+    // the bias sums ride along; a second fragment set on top of two global register sets spilled inside the loop, and a
+    // spill reload is a vmcnt(0) wait that drains the prefetch.
+    auto compute = [&](int buf, int s) {
+        const unsigned char* sP = smem + buf * BUF;
+        const unsigned char* sQ = sP + G::MT * G::ROWB;
+        frag af[4], bf[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            frag af[4], bf[4];
+        for (int a = 0; a < 4; ++a) af[a] = tn_frag(sP, wr * 64 + a * 16, s, lane, (CT*)nullptr);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = tn_frag(sP, wr * 64 + a * 16, s, lane, (CT*)nullptr);
+        for (int b = 0; b < 4; ++b) bf[b] = tn_frag(sQ, wc * 64 + b * 16, s, lane, (CT*)nullptr);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bf[b] = tn_frag(sQ, wc * 64 + b * 16, s, lane, (CT*)nullptr);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Mma<CT>::mma(acc[a][b], af[a], bf[b]);
+        if (do_bias) {                      // column sums of P straight from the A fragments (VALU is idle here)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) Mma<CT>::mma(acc[a][b], af[a], bf[b]);
-            if (do_bias) {                      // column sums of P straight from the A fragments (VALU is idle here)
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int j = 0; j < Mma<CT>::EPC; ++j) bsum[a] += to_f32(af[a][j]);
-            }
+                for (int j = 0; j < Mma<CT>::EPC; ++j) bsum[a] += to_f32(af[a][j]);
         }
+    };
+    // one batch step: tile t is multiplied from LDS buffer `buf` while tile t+1 goes registers -> other buffer between the
+    // two fragment steps and a later tile is fetched into the registers just freed; ONE barrier per step
+#ifdef MM_STAMP
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, t_first = 0, t_last = 0, st_acc5 = 0;
+    MT_T(t_begin);
+#endif
+    auto kstep = [&](auto& rp_n, auto& rq_n, int t, int buf, bool has_next, bool do_fetch, int fetch_t) {
+        MT_T(t0);
+        compute(buf, 0);
+        MT_T(t1);
+#ifdef MM_STAMP
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // steady state: the set about to be staged has landed
+        MT_T(t1b);
+        st_acc5 += t1b - t1;
+#endif
+        if (has_next) stage(rp_n, rq_n, t + 1, buf ^ 1);
+        MT_T(t2);
+        compute(buf, 1);
+        if (do_fetch) fetch(rp_n, rq_n, fetch_t);
+#ifdef MM_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        MT_T(t3);
         __syncthreads();
+        MT_T(t4);
+#ifdef MM_STAMP
+        if (st_acc[4] == 0) t_first = t0;
+        t_last = t4;
+        st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += 1;
+#endif
+    };
+    // f32 sources hold 32 bytes per chunk in flight: two sets of those spill, so they run one set, one step ahead
+    constexpr bool TWO_SETS = sizeof(typename PSrc::Raw) + sizeof(typename QSrc::Raw) <= 40;
+    if constexpr (!TWO_SETS) {
+        fetch(rp0, rq0, 0);
+        stage(rp0, rq0, 0, 0);
+        if (nt > 1) fetch(rp0, rq0, 1);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            compute(t & 1, 0);
+            if (t + 1 < nt) stage(rp0, rq0, t + 1, (t + 1) & 1);
+            compute(t & 1, 1);
+            if (t + 2 < nt) fetch(rp0, rq0, t + 2);
+            __syncthreads();
+        }
+    } else if (nt >= 5) {
+        fetch(rp0, rq0, 0);
+        fetch(rp1, rq1, 1);
+        stage(rp0, rq0, 0, 0);
+        fetch(rp0, rq0, 2);
+        __syncthreads();
+        int t = 0;
+        for (; t + 4 < nt; t += 2) {
+            kstep(rp1, rq1, t, 0, true, true, t + 3);
+            kstep(rp0, rq0, t + 1, 1, true, true, t + 4);
+        }
+        const bool four = t + 3 < nt;
+        kstep(rp1, rq1, t, 0, true, four, t + 3);
+        kstep(rp0, rq0, t + 1, 1, true, false, 0);
+        kstep(rp1, rq1, t + 2, 0, four, false, 0);
+        if (four) kstep(rp1, rq1, t + 3, 1, false, false, 0);
+    } else {
+        fetch(rp0, rq0, 0);
+        if (nt > 1) fetch(rp1, rq1, 1);
+        stage(rp0, rq0, 0, 0);
+        if (nt > 2) fetch(rp0, rq0, 2);
+        __syncthreads();
+        kstep(rp1, rq1, 0, 0, nt > 1, nt > 3, 3);
+        if (nt > 1) kstep(rp0, rq0, 1, 1, nt > 2, false, 0);
+        if (nt > 2) kstep(rp1, rq1, 2, 0, nt > 3, false, 0);
+        if (nt > 3) kstep(rp1, rq1, 3, 1, false, false, 0);
     }
 
 #pragma unroll
@@ -175,120 +259,27 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             if (lane < 16 && n < N) unsafeAtomicAdd(db + n, v);
         }
     }
+#ifdef MM_STAMP
+    if (tid == 0 && (blockIdx.x & 7) == 3) {
+        MT_T(t_end);
+        for (int i = 0; i < 5; ++i) atomicAdd(&mm_stamps_tn[i], st_acc[i]);
+        atomicAdd(&mm_stamps_tn[5], 1ull);
+        atomicAdd(&mm_stamps_tn[6], t_end - t_begin);
+        atomicAdd(&mm_stamps_tn[7], st_acc5);
+        atomicAdd(&mm_stamps_tn[8], t_first - t_begin);
+        atomicAdd(&mm_stamps_tn[9], t_end - t_last);
+    }
+#endif
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS-ring variant for plain bf16 operands (see gemm_ring.h): P and Q tiles ([64 m][128 cols] bf16,
-// 16 KiB each) are DMA'd straight into a 4-stage ring; the tr16 swizzle goes on the source address.
-// Rows past M read as zeros through the buffer resource; columns past N / K only feed accumulators
-// that are never stored.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS, 1)
-void gemm_tn_ring_kernel(const bf16* __restrict__ P, long ldp, unsigned p_bytes, const bf16* __restrict__ Q, long ldq, unsigned q_bytes,
-                         float* __restrict__ dW, long ldw, float* __restrict__ db,
-                         int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
-{
-    typedef TnGeom<bf16> G;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int L = blockIdx.x, slot = L >> 3;
-    const int tile = slot % ntiles;
-    const int zz = (slot / ntiles) * 8 + (L & 7);
-    if (zz >= nsplit) return;
-    const int tn = tile / ntk, tk = tile % ntk;
-    const int n0 = tn * TILE, k0 = tk * TILE;
-    const int m_begin = zz * rows_per_split;              // multiple of 64: only the global tail is ragged
-    const int m_end = min(M, m_begin + rows_per_split);
-    if (m_begin >= m_end) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
-
-    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, q_bytes, 0x00020000);
-    // piece p (1 KiB) = tile rows 4p..4p+3 (256-byte rows); lane -> row 4p + (lane>>4), physical chunk lane&15,
-    // holding logical chunk (((phys>>1) ^ f(row)) << 1) | (phys & 1)   (inverse of TnGeom::chunk_off)
-    unsigned p_off[4], q_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 4 * (wid + 4 * i) + (lane >> 4), ph = lane & 15;
-        const int ch = ((((ph >> 1) ^ G::f(r)) << 1) | (ph & 1));
-        p_off[i] = (unsigned)(((long)(m_begin + r) * ldp + n0 + ch * 8) * 2);
-        q_off[i] = (unsigned)(((long)(m_begin + r) * ldq + k0 + ch * 8) * 2);
-    }
-    const unsigned p_step = (unsigned)(64 * ldp * 2), q_step = (unsigned)(64 * ldq * 2);
-    auto issue = [&](int t) {
-        unsigned char* st = smem + (t % RING_NS) * RING_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = wid + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void*)(st + p * 1024), 16, p_off[i] + t * p_step, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(st + 16384 + p * 1024), 16, q_off[i] + t * q_step, 0, 0, 0);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (db != nullptr) && tk == 0 && wc == 0;
-    const int nt = (m_end - m_begin + G::MT - 1) / G::MT;
-
-#pragma unroll
-    for (int s = 0; s < RING_NS - 1; ++s) if (s < nt) issue(s);
-    for (int t = 0; t < nt; ++t) {
-        ring_wait(min(RING_NS - 2, nt - 1 - t));
-        ring_barrier();
-        if (t + RING_NS - 1 < nt) issue(t + RING_NS - 1);
-        const unsigned char* sP = smem + (t % RING_NS) * RING_STAGE;
-        const unsigned char* sQ = sP + 16384;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = tn_frag(sP, wr * 64 + a * 16, s, lane, (bf16*)nullptr);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) bfr[b] = tn_frag(sQ, wc * 64 + b * 16, s, lane, (bf16*)nullptr);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) Mma<bf16>::mma(acc[a][b], af[a], bfr[b]);
-            if (do_bias) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum[a] += to_f32(af[a][j]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wr * 64 + a * 16 + (lane >> 4) * 4 + j;
-            if (n >= N) continue;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = k0 + wc * 64 + b * 16 + (lane & 15);
-                if (k < K) {
-                    if (slab) slab[((long)zz * N + n) * K + k] = acc[a][b][j];
-                    else unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
-                }
-            }
-        }
-    if (do_bias) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float v = bsum[a];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            const int n = n0 + wr * 64 + a * 16 + lane;
-            if (lane < 16 && n < N) unsafeAtomicAdd(db + n, v);
-        }
-    }
+#ifdef MM_STAMP
+extern "C" int mmvae_debug_stamps_tn(unsigned long long* out12, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(mm::mm_stamps_tn), 12 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    if (reset) { unsigned long long z[12] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(mm::mm_stamps_tn), z, sizeof(z)); }
+    return (int)e;
 }
+#endif
 
 // dW[n][k] += sum_z slab[z][n][k]   (fixed summation order -> bitwise reproducible weight gradients)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, int nsplit, long nk, float* __restrict__ dW,
@@ -337,24 +328,6 @@ static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int&
     nsplit = (M + rps - 1) / rps;
 }
 
-static int launch_tn_ring(const mmvae_gemm_tn_args* a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    int ntk, ntiles, nsplit, rps;
-    tn_split(a->M, a->N, a->K, 64, a->nsplit, ntk, ntiles, nsplit, rps);
-    const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
-    float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
-    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(grid), dim3(NTHREADS), RING_LDS, st,
-                       (const bf16*)a->p, a->ldp, (unsigned)((long)a->M * a->ldp * 2), (const bf16*)a->q, a->ldq,
-                       (unsigned)((long)a->M * a->ldq * 2), a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
-    MM_CHECK_LAUNCH();
-    return slab ? tn_reduce(a, nsplit, st) : 0;
-}
-
 template <typename CT, typename PSrc, typename QSrc>
 static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs, hipStream_t st) {
     typedef TnGeom<CT> G;
@@ -362,7 +335,14 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
     float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
-    hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), 0, st, ps, qs,
+    constexpr int LDS = 4 * G::MT * G::ROWB + 4096;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), LDS, st, ps, qs,
                        a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
     MM_CHECK_LAUNCH();
     return slab ? tn_reduce(a, nsplit, st) : 0;
@@ -420,12 +400,7 @@ extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if ((long)a->M * a->ldp * (a->p_dtype == MMVAE_BF16 ? 2 : 4) >= lim || (long)a->M * a->ldq * (a->q_dtype == MMVAE_BF16 ? 2 : 4) >= lim) return MMVAE_ERR_ARG;
     if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (a->prec == MMVAE_PREC_BF16) {
-        if (a->p_dtype == MMVAE_BF16 && a->q_dtype == MMVAE_BF16 && a->q_prologue == MMVAE_PRO_NONE &&
-            mm::ring_ok(a->p, a->ldp, a->M) && mm::ring_ok(a->q, a->ldq, a->M))
-            return mm::launch_tn_ring(a, st);
-        return mm::tn_dispatch_p<mm::bf16>(a, st);
-    }
+    if (a->prec == MMVAE_PREC_BF16) return mm::tn_dispatch_p<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::tn_dispatch_p<float>(a, st);
     return MMVAE_ERR_ARG;
 }
