@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of single GEMM launches (through the C ABI) for kernel tuning:
 time vs K (slope = cost of one K step, intercept = prologue + epilogue) and the hot-path shapes.
-    MMVAE_RING=1 python tools/bench_gemm.py        # LDS-ring kernels for plain bf16 operands
+
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +47,7 @@ def tn(N, K, q_dtype=torch.bfloat16, nsplit=0):
     return timeit(lambda: ops.gemm_tn(PREC_BF16, P, Q, dw, db, N, K, nsplit=nsplit))
 
 
-print("ring enabled" if os.environ.get("MMVAE_RING") else "ring disabled", "M =", M)
+print("M =", M)
 print("NT bf16->bf16 N=128, K sweep:", [(K, round(nt(128, K), 1)) for K in (64, 128, 256, 512, 1024)])
 print("NT bf16->bf16 N=512, K sweep:", [(K, round(nt(512, K), 1)) for K in (64, 128, 256, 512, 1024)])
 print("NT bf16->f32  N=572 K=512 (DecB.L2.fwd):", round(nt(572, 512, out_dtype=torch.float32), 1))

@@ -203,7 +203,7 @@ __device__ __forceinline__ void nt_epilogue_fill_cols(float* ecol, const Epi& ep
 // ~5000 instructions per lane (8-10 k cycles per tile, as much as 5 K steps); this one ~600.
 template <typename Epi, int ACT, bool ACCUM, bool VEC>
 __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)[4][4], const Epi& epi, const EpiOperands<Epi>& ops,
-                                                 float (&s1)[16], float (&s2)[16], int BN, int row0, int col0, int M, int N, int lane, int wr, int wc)
+                                                 float* red, bool want_stats, int BN, int row0, int col0, int M, int N, int lane, int wr, int wc)
 {
     typedef typename Epi::out_t OT;
     typedef typename Epi::h_t HT;
@@ -222,6 +222,9 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
         typename Epi::Col cc[G];
 #pragma unroll
         for (int e = 0; e < G; ++e) cc[e] = epi.col(ecol, BN, cw + e);
+        float s1[G], s2[G];                                     // column partial sums of this group, over the lane's 4 rows
+#pragma unroll
+        for (int e = 0; e < G; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = row0 + wr * 64 + m * 16 + li;
@@ -263,7 +266,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
             for (int e = 0; e < G; ++e) {
                 const int n = EC::tile(g, e), j = e & 3;
                 const bool ok = rok && (c0 + e < N);
-                float v = epi.template compute<ACT>(acc[m][n][j], hv[e], mb[e], cc[e], ok, s1[n * 4 + j], s2[n * 4 + j]);
+                float v = epi.template compute<ACT>(acc[m][n][j], hv[e], mb[e], cc[e], ok, s1[e], s2[e]);
                 if constexpr (ACCUM) v += o[e];
                 o[e] = (c0 + e < N) ? v : 0.f;
             }
@@ -287,6 +290,29 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
                 }
             }
         }
+        if (Epi::STATS && want_stats) {
+            // Column sums of this group over the 16 lanes li of a lane group, per group so that only 2*G partials are live:
+            // reduce-scatter butterfly -- each step a lane keeps the half of its values selected by one bit of li and adds
+            // the partner's copy of that half.  v index = which*G + e; the bits of li, from 8 down, select which, then e.
+            float v[2 * G];
+#pragma unroll
+            for (int e = 0; e < G; ++e) { v[e] = s1[e]; v[G + e] = s2[e]; }
+            int bit = 8;
+#pragma unroll
+            for (int half = G; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (li & bit) != 0;
+#pragma unroll
+                for (int i = 0; i < half; ++i) {
+                    const float keep = up ? v[i + half] : v[i];
+                    const float send = up ? v[i] : v[i + half];
+                    v[i] = keep + __shfl_xor(send, bit, 64);
+                }
+            }
+            if constexpr (G == 4) v[0] += __shfl_xor(v[0], 1, 64);      // 8 values, 16 lanes: the last bit is a plain add
+            const int which = li >> 3;
+            const int e = G == 8 ? (li & 7) : ((li >> 1) & 3);
+            if (G == 8 || (li & 1) == 0) red[(wr * 2 + which) * BN + cw + e] = v[0];
+        }
     }
 }
 
@@ -298,46 +324,21 @@ __device__ __forceinline__ void nt_epilogue(float* red, const float* ecol, f32x4
     constexpr int BN = 64 * WN;
     typedef EpiOperands<Epi> EO;
     typedef typename EO::EC EC;
-    const int li = lane & 15, lg = lane >> 4;
-    float s1[16], s2[16];                                       // per accumulator (n, j): index 4n + j
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    const bool want_stats = Epi::STATS && (epi.stat1 != nullptr || epi.stat2 != nullptr);
     // operands arrive as prefetched vectors unless a leading dimension / base address rules 16-byte accesses out
     const bool vec = (Epi::NEED < 1 || epi_h_vec(epi)) && (Epi::NEED < 2 || epi.mask == nullptr || epi_m_vec(epi));
     if (epi.accum()) {
-        nt_epilogue_body<Epi, -1, true, false>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+        nt_epilogue_body<Epi, -1, true, false>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
     } else if (!vec) {
-        nt_epilogue_body<Epi, -1, false, false>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+        nt_epilogue_body<Epi, -1, false, false>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
     } else {
         nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, lane, wr, wc);
         const int a = epi.act_code();
-        if (a == 0) nt_epilogue_body<Epi, 0, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
-        else if (a == 1) nt_epilogue_body<Epi, 1, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
-        else nt_epilogue_body<Epi, 2, false, true>(ecol, acc, epi, ops, s1, s2, BN, row0, col0, M, N, lane, wr, wc);
+        if (a == 0) nt_epilogue_body<Epi, 0, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
+        else if (a == 1) nt_epilogue_body<Epi, 1, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
+        else nt_epilogue_body<Epi, 2, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
     }
-    if (Epi::STATS && (epi.stat1 != nullptr || epi.stat2 != nullptr)) {
-        // Column sums: 32 partials per lane (s1 / s2 of 16 accumulator columns) over the 16 lanes li of a lane group.
-        // Reduce-scatter butterfly (xor 8, 4, 2, 1: 16 + 8 + 4 + 2 shuffles): each step a lane keeps the half of its
-        // values selected by one bit of li and adds the partner's copy of that half.  v index = which*16 + n*4 + j, so lane
-        // li ends up with which = li >> 3, n = (li >> 1) & 3, j = 2*(li & 1) + {0, 1} (two adjacent columns in either order).
-        float v[32];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { v[i] = s1[i]; v[16 + i] = s2[i]; }
-#pragma unroll
-        for (int step = 0; step < 4; ++step) {
-            const int bit = 8 >> step, half = 16 >> step;
-            const bool up = (li & bit) != 0;
-#pragma unroll
-            for (int i = 0; i < half; ++i) {
-                const float keep = up ? v[i + half] : v[i];
-                const float send = up ? v[i] : v[i + half];
-                v[i] = keep + __shfl_xor(send, bit, 64);
-            }
-        }
-        const int which = li >> 3;
-        const int cl = wc * 64 + EC::wrow(((li >> 1) & 3) * 16 + lg * 4 + 2 * (li & 1));
-        red[(wr * 2 + which) * BN + cl] = v[0];
-        red[(wr * 2 + which) * BN + cl + 1] = v[1];
+    if (want_stats) {
         __syncthreads();
         if (tid < BN && col0 + tid < N) {
             if (epi.stat1) unsafeAtomicAdd(epi.stat1 + col0 + tid, (double)(red[0 * BN + tid] + red[2 * BN + tid]));

@@ -191,8 +191,9 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
         st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += 1;
 #endif
     };
-    // f32 sources hold 32 bytes per chunk in flight: two sets of those spill, so they run one set, one step ahead
-    constexpr bool TWO_SETS = sizeof(typename PSrc::Raw) + sizeof(typename QSrc::Raw) <= 40;
+    // f32 sources hold 32 bytes per chunk in flight (two sets spill) and the BN-prologue source measured slower with two:
+    // those run one register set, one step ahead
+    constexpr bool TWO_SETS = sizeof(typename PSrc::Raw) + sizeof(typename QSrc::Raw) <= 32;       // plain bf16 x plain bf16 only
     if constexpr (!TWO_SETS) {
         fetch(rp0, rq0, 0);
         stage(rp0, rq0, 0, 0);
