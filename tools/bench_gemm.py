@@ -57,3 +57,36 @@ print("NT f32->bf16  N=512 K=572 (EncB.L0.fwd):", round(nt(512, 572, a_dtype=tor
 print("TN N=572 K=512 split sweep:", [(s, round(tn(572, 512, nsplit=s), 1)) for s in (0, 8, 16, 32, 64)])
 print("TN N=512 K=572 f32 Q (EncB.L0.dW):", round(tn(512, 572, q_dtype=torch.float32), 1))
 print("TN N=782 K=128 (DecA.L1.dW):", round(tn(782, 128), 1))
+
+
+def nt_bn_bwd(N, K, a_dtype=torch.bfloat16, with_stats=True):
+    """dX GEMM with the BatchNorm-backward epilogue (phase 2: store d + column statistics; phase 1: apply, no statistics)."""
+    A = torch.randn(M, ops.ceil_to(K, 8), device=dev).to(a_dtype)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    pl = ops.PreparedLinear([W], [torch.zeros(N, device=dev)], PREC_BF16, dev)
+    ops.WeightPrep([pl], dev).run()
+    y = torch.randn(M, N, device=dev).bfloat16()
+    mask = (torch.rand(M, N, device=dev) > 0.1).to(torch.uint8)
+    f = lambda: torch.rand(N, device=dev) + 0.5
+    bn = (f(), f() - 1.0, f() - 1.0, f(), mask, 1.0 / 0.9)
+    d = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+    coef = torch.rand(3, N, device=dev)
+    if with_stats:
+        return timeit(lambda: ops.gemm_nt(PREC_BF16, A, pl.w, N, K, d, epilogue=ops.EPI_BN_BWD, h=y, bn=bn, bn_phase=2, stats=stats))
+    return timeit(lambda: ops.gemm_nt(PREC_BF16, A, pl.w, N, K, d, epilogue=ops.EPI_BN_BWD, h=y, bn=bn, bn_coef=coef))
+
+
+def nt_stats(N, K, a_dtype=torch.float32, with_stats=True):
+    A = torch.randn(M, ops.ceil_to(K, 8) if a_dtype == torch.bfloat16 else K, device=dev).to(a_dtype)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    pl = ops.PreparedLinear([W], [torch.zeros(N, device=dev)], PREC_BF16, dev)
+    ops.WeightPrep([pl], dev).run()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+    return timeit(lambda: ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, stats=stats if with_stats else None))
+
+
+print("NT BN-bwd epilogue N=512 K=256 (EncB.L0.dX): with stats", round(nt_bn_bwd(512, 256), 1), " apply phase, no stats", round(nt_bn_bwd(512, 256, with_stats=False), 1))
+print("NT BN-bwd epilogue N=256 K=40 f32 A (EncB.L1.dX): with stats", round(nt_bn_bwd(256, 40, a_dtype=torch.float32), 1), " no stats", round(nt_bn_bwd(256, 40, a_dtype=torch.float32, with_stats=False), 1))
+print("NT f32->bf16 N=512 K=572 (EncB.L0.fwd): with stats", round(nt_stats(512, 572), 1), " without", round(nt_stats(512, 572, with_stats=False), 1))

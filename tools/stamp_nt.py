@@ -22,7 +22,10 @@ M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 dev = "cuda"
 lib = L.load()
 lib.mmvae_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-A = [torch.randn(M, K, device=dev).bfloat16() for _ in range(3)]
+SRC_F32 = os.environ.get("SRC") == "f32"
+STATS = os.environ.get("STATS") == "1"
+A = [torch.randn(M, K, device=dev) if SRC_F32 else torch.randn(M, K, device=dev).bfloat16() for _ in range(3)]
+stats = torch.zeros(2, N, dtype=torch.float64, device=dev) if STATS else None
 W = torch.randn(N, K, device=dev) / 30
 bias = torch.zeros(N, device=dev)
 pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev)
@@ -33,7 +36,7 @@ buf = (C.c_uint64 * 12)()
 
 def run(reps):
     for i in range(reps):
-        ops.gemm_nt(PREC_BF16, A[i % 3], pl.w, N, K, out, bias=pl.bias)
+        ops.gemm_nt(PREC_BF16, A[i % 3], pl.w, N, K, out, bias=pl.bias, stats=stats)
     torch.cuda.synchronize()
 
 

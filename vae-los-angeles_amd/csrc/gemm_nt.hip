@@ -204,17 +204,28 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         kstep(ra1, rb1, kt + 2, 0, four, false, 0);
         if (four) { pre(); kstep(ra1, rb1, kt + 3, 1, false, false, 0); }
     } else {
+        // Short K (nk <= 4: the 64 / 128 / 256-wide layers and the latent): conditional fetches, so the waits are coarse
+        // anyway; ONE fragment set here -- with two, the conditional form spilled (scratch reloads wait vmcnt(0), i.e. for
+        // every load in flight: the K = 256 BatchNorm-backward layer ran at 12 % of the HBM roofline).
+        auto kstep1 = [&](auto& ra_n, auto& rb_n, int kt, int buf, bool has_next, bool do_fetch, int fetch_kt) {
+            rd(f0a, f0b, buf, 0);
+            mma(f0a, f0b);
+            if (has_next) stage(ra_n, rb_n, kt + 1, buf ^ 1);
+            rd(f0a, f0b, buf, 1);
+            mma(f0a, f0b);
+            if (do_fetch) fetch(ra_n, rb_n, fetch_kt);
+            __syncthreads();
+        };
         fetch(ra0, rb0, 0);
         if (nk > 1) fetch(ra1, rb1, 1);
         stage(ra0, rb0, 0, 0);
         if (nk > 2) fetch(ra0, rb0, 2);
         __syncthreads();
-        rd(f0a, f0b, 0, 0);
         if (nk == 1) pre();
-        kstep(ra1, rb1, 0, 0, nk > 1, nk > 3, 3);
-        if (nk > 1) { if (nk == 2) pre(); kstep(ra0, rb0, 1, 1, nk > 2, false, 0); }
-        if (nk > 2) { if (nk == 3) pre(); kstep(ra1, rb1, 2, 0, nk > 3, false, 0); }
-        if (nk > 3) { pre(); kstep(ra1, rb1, 3, 1, false, false, 0); }
+        kstep1(ra1, rb1, 0, 0, nk > 1, nk > 3, 3);
+        if (nk > 1) { if (nk == 2) pre(); kstep1(ra0, rb0, 1, 1, nk > 2, false, 0); }
+        if (nk > 2) { if (nk == 3) pre(); kstep1(ra1, rb1, 2, 0, nk > 3, false, 0); }
+        if (nk > 3) { pre(); kstep1(ra1, rb1, 3, 1, false, false, 0); }
     }
 
     nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);

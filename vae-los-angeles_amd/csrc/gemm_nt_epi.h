@@ -290,6 +290,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
                 }
             }
         }
+#ifndef MM_NO_STAT_REDUCE
         if (Epi::STATS && want_stats) {
             // Column sums of this group over the 16 lanes li of a lane group, per group so that only 2*G partials are live:
             // reduce-scatter butterfly -- each step a lane keeps the half of its values selected by one bit of li and adds
@@ -300,11 +301,14 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
             int bit = 8;
 #pragma unroll
             for (int half = G; half >= 1; half >>= 1, bit >>= 1) {
-                const bool up = (li & bit) != 0;
+                // bit-select, NOT `up ? v[i + half] : v[i]`: LLVM folds a select of two array elements into one dynamically
+                // indexed access, i.e. a 16-deep v_cmp / v_cndmask chain per value (20 k cycles per tile, measured)
+                const unsigned up = (li & bit) ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int i = 0; i < half; ++i) {
-                    const float keep = up ? v[i + half] : v[i];
-                    const float send = up ? v[i] : v[i + half];
+                    const unsigned lo = __float_as_uint(v[i]), hi = __float_as_uint(v[i + half]);
+                    const float keep = __uint_as_float((hi & up) | (lo & ~up));
+                    const float send = __uint_as_float((lo & up) | (hi & ~up));
                     v[i] = keep + __shfl_xor(send, bit, 64);
                 }
             }
@@ -313,6 +317,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
             const int e = G == 8 ? (li & 7) : ((li >> 1) & 3);
             if (G == 8 || (li & 1) == 0) red[(wr * 2 + which) * BN + cw + e] = v[0];
         }
+#endif
     }
 }
 
@@ -340,10 +345,12 @@ __device__ __forceinline__ void nt_epilogue(float* red, const float* ecol, f32x4
     }
     if (want_stats) {
         __syncthreads();
+#ifndef MM_NO_STAT_ATOMICS
         if (tid < BN && col0 + tid < N) {
             if (epi.stat1) unsafeAtomicAdd(epi.stat1 + col0 + tid, (double)(red[0 * BN + tid] + red[2 * BN + tid]));
             if (epi.stat2) unsafeAtomicAdd(epi.stat2 + col0 + tid, (double)(red[1 * BN + tid] + red[3 * BN + tid]));
         }
+#endif
     }
 }
 
