@@ -39,6 +39,18 @@ elif tag == "DecoderB.L2.fwd":         # recon_b[B,572] = sigmoid(H2 W^T + b), f
     pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
     out = torch.empty(M, 572, device=dev)
     run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, 572, 512, out, bias=pl.bias, act=ops.ACT_SIGMOID)
+elif tag in ("EncoderB.L0.dX", "EncoderB.L1.dX"):   # dX GEMM with the BatchNorm-backward epilogue (store d + column statistics)
+    N, K = (512, 256) if tag == "EncoderB.L0.dX" else (256, 40)
+    A = bf(M, K) if tag == "EncoderB.L0.dX" else [torch.randn(M, K, device=dev) for _ in range(nbuf)]
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    pl = ops.PreparedLinear([W], [torch.zeros(N, device=dev)], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
+    Y = bf(M, N)
+    mask = [(torch.rand(M, N, device=dev) > 0.1).to(torch.uint8) for _ in range(nbuf)]
+    f = lambda: torch.rand(N, device=dev) + 0.5
+    sc, sh, mu, rs = f(), f() - 1.0, f() - 1.0, f()
+    d = torch.empty(M, N, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, N, dtype=torch.float64, device=dev)
+    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, N, K, d, epilogue=ops.EPI_BN_BWD, h=Y[i % nbuf],
+                                bn=(sc, sh, mu, rs, mask[i % nbuf], 1.0 / 0.9), bn_phase=2, stats=st)
 else:
     raise SystemExit(f"unknown tag {tag}")
 for i in range(reps):

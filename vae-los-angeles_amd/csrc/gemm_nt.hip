@@ -176,7 +176,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     };
 
     EpiOperands<Epi> eops;
-    auto pre = [&]() { nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, lane, wr, wc); };     // no-op unless the operands are 16-byte addressable
+    auto pre = [&]() { nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc); };     // no-op unless the operands are 16-byte addressable
 
     // hipcc's s_waitcnt insertion is only as precise as the control flow lets it be: a fetch under `if (kt + 3 < nk)`
     // means "maybe 8 fewer loads in flight" at the next stage(), and the wait degrades to vmcnt(0) -- every K step then

@@ -143,28 +143,46 @@ struct EpiOperands {
 template <typename Epi> __device__ __forceinline__ bool epi_h_vec(const Epi& epi) {
     return Epi::NEED >= 1 && (epi.ldh * sizeof(typename Epi::h_t)) % 16 == 0 && ((uintptr_t)epi.H & 15) == 0;
 }
+// H rows are whole 128-byte lines and the tile's columns exist: H is then LOADED in the same full-line layout the stores
+// use (8 lanes x 16 bytes per row and instruction) and swapped back into accumulator layout when it is used; loading the
+// two 64-byte halves of a line from separate instructions cost +40 % HBM read traffic (FETCH_SIZE), the line having left
+// the L2 before its second half was asked for.
+template <typename Epi> __device__ __forceinline__ bool epi_h_lines(const Epi& epi, int col0, int BN) {
+    return epi_h_vec(epi) && (epi.ldh * sizeof(typename Epi::h_t)) % 128 == 0 && ((uintptr_t)epi.H & 127) == 0 && col0 + BN <= epi.ldh;
+}
 template <typename Epi> __device__ __forceinline__ bool epi_m_vec(const Epi& epi) {
     return Epi::NEED >= 2 && epi.mask != nullptr && epi.ldm % 8 == 0 && ((uintptr_t)epi.mask & 7) == 0;
 }
 
 // Branch-free (clamped addresses): these loads are issued between K steps, where a conditional load would cost the
 // counted vmcnt waits of the remaining stage() calls (see gemm_src.h).  wr/wc: wave row/column inside the tile.
-// HALF 0: the groups the epilogue consumes first (issued before the last K step); HALF 1: the rest (issued when the
-// epilogue starts, covered by the work on the first half) -- all 48 operand registers at once did not fit next to the
-// accumulators and both fragment sets, and hipcc spilled the values it had just loaded.
+// HALF 0: rows m = 0, 1 (issued before the last K step); HALF 1: m = 2, 3 (issued when the epilogue starts, covered by
+// the work on the first half) -- all 48 operand registers at once did not fit next to the accumulators and both
+// fragment sets, and hipcc spilled the values it had just loaded.
 template <typename Epi, int HALF>
-__device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, const Epi& epi, int row0, int col0, int M, int lane, int wr, int wc) {
+__device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, const Epi& epi, int row0, int col0, int M, int BN, int lane, int wr, int wc) {
     typedef EpiOperands<Epi> EO;
     typedef typename EO::EC EC;
     const int li = lane & 15, lg = lane >> 4;
     if constexpr (Epi::NEED >= 1) {
-        if (epi_h_vec(epi)) {
+        if (epi_h_lines(epi, col0, BN)) {
+            // slot 2p holds (row 16m + (li & 7), half li >> 3), slot 2p+1 the same half of row 16m + 8 + (li & 7)
 #pragma unroll
-            for (int g = HALF * EC::NG / 2; g < (HALF + 1) * EC::NG / 2; ++g) {      // g-major: the order in which the epilogue consumes them
-                const int c = col0 + wc * 64 + EC::base(g, lg);
+            for (int m = 2 * HALF; m < 2 * HALF + 2; ++m)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldh;
+                for (int g = 0; g < EC::NG; ++g) {
+                    const int r = row0 + wr * 64 + m * 16 + (g & 1) * 8 + (li & 7);
+                    const int c = col0 + wc * 64 + EC::base((g & ~1) + (li >> 3), lg);
+                    const uint4 t = *(const uint4*)(epi.H + (long)min(r, M - 1) * epi.ldh + c);
+                    ops.h[m * EC::NG + g][0] = t.x; ops.h[m * EC::NG + g][1] = t.y; ops.h[m * EC::NG + g][2] = t.z; ops.h[m * EC::NG + g][3] = t.w;
+                }
+        } else if (epi_h_vec(epi)) {
+#pragma unroll
+            for (int m = 2 * HALF; m < 2 * HALF + 2; ++m) {
+                const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldh;
+#pragma unroll
+                for (int g = 0; g < EC::NG; ++g) {
+                    const int c = col0 + wc * 64 + EC::base(g, lg);
                     const uint4 t = *(const uint4*)(epi.H + ro + (c + EC::G <= epi.ldh ? c : 0));
                     ops.h[m * EC::NG + g][0] = t.x; ops.h[m * EC::NG + g][1] = t.y; ops.h[m * EC::NG + g][2] = t.z; ops.h[m * EC::NG + g][3] = t.w;
                 }
@@ -174,11 +192,11 @@ __device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, cons
     if constexpr (Epi::NEED >= 2) {
         if (epi_m_vec(epi)) {
 #pragma unroll
-            for (int g = HALF * EC::NG / 2; g < (HALF + 1) * EC::NG / 2; ++g) {
-                const int c = col0 + wc * 64 + EC::base(g, lg);
+            for (int m = 2 * HALF; m < 2 * HALF + 2; ++m) {
+                const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldm;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const long ro = (long)min(row0 + wr * 64 + m * 16 + li, M - 1) * epi.ldm;
+                for (int g = 0; g < EC::NG; ++g) {
+                    const int c = col0 + wc * 64 + EC::base(g, lg);
                     const uint8_t* q = epi.mask + ro + (c + EC::G <= epi.ldm ? c : 0);
                     if constexpr (EO::MD == 2) { const uint2 t = *(const uint2*)q; ops.mk[m * EC::NG + g][0] = t.x; ops.mk[m * EC::NG + g][1] = t.y; }
                     else ops.mk[m * EC::NG + g][0] = *(const uint32_t*)q;
@@ -216,106 +234,151 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
     const bool c16 = (epi.ldc * sizeof(OT)) % 16 == 0 && ((uintptr_t)epi.C & 15) == 0;     // whole-group vector stores
     const bool c8 = (epi.ldc * sizeof(OT)) % 8 == 0 && ((uintptr_t)epi.C & 7) == 0;
     const bool has_mask = Epi::NEED >= 2 && epi.mask != nullptr;
+    // Groups 2p and 2p+1 are the two 64-byte halves of one 128-byte line of the row.  When the whole tile is interior and
+    // rows are 128-byte aligned, lanes li and li^8 swap one half each so that every store instruction writes 8 rows x one
+    // FULL line (8 lanes x 16 bytes); storing the halves from separate instructions cost +55 % HBM write traffic
+    // (rocprofv3 WRITE_SIZE: 104 MB for a 67 MB output) -- the L2 wrote the partial lines back twice.
+    const bool full_lines = !ACCUM && epi.stores() && row0 + TILE <= M && col0 + BN <= n_store &&
+                            (epi.ldc * sizeof(OT)) % 128 == 0 && ((uintptr_t)epi.C & 127) == 0;
+    const unsigned low = (li & 8) ? 0u : 0xffffffffu;           // all-ones on lanes li < 8
+    const bool h_lines = VEC && Epi::NEED >= 1 && epi_h_lines(epi, col0, BN);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int cw = wc * 64 + EC::base(g, lg), c0 = col0 + cw;
-        typename Epi::Col cc[G];
+    for (int p = 0; p < NG / 2; ++p) {
+        float s1[2][G], s2[2][G];                               // column partial sums of the two groups, over the lane's 4 rows
 #pragma unroll
-        for (int e = 0; e < G; ++e) cc[e] = epi.col(ecol, BN, cw + e);
-        float s1[G], s2[G];                                     // column partial sums of this group, over the lane's 4 rows
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < G; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+            for (int e = 0; e < G; ++e) { s1[h][e] = 0.f; s2[h][e] = 0.f; }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = row0 + wr * 64 + m * 16 + li;
             const bool rok = row < M;
-            float hv[G]; unsigned mb[G]; float o[G];
+            uint32_t pk[2][4];                                  // the two 16-byte pieces of this lane, packed for the store
+            uint32_t hw[2][4];                                  // H of this lane's two groups, accumulator layout
+            if constexpr (Epi::NEED >= 1 && VEC) {
 #pragma unroll
-            for (int e = 0; e < G; ++e) { hv[e] = 0.f; mb[e] = 1u; o[e] = 0.f; }
-            if constexpr (Epi::NEED >= 1) {
-                if constexpr (VEC) {
-#pragma unroll
-                    for (int e = 0; e < G; ++e) {
-                        if constexpr (sizeof(HT) == 2) {
-                            const uint32_t w = ops.h[m * NG + g][e >> 1];
-                            hv[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
-                        } else hv[e] = __uint_as_float(ops.h[m * NG + g][e]);
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t l0 = ops.h[m * NG + 2 * p][q], l1 = ops.h[m * NG + 2 * p + 1][q];
+                    hw[0][q] = l0; hw[1][q] = l1;
+                    if (h_lines) {                              // loaded in full-line layout: swap back (see epi_h_lines)
+                        const uint32_t got = (uint32_t)__shfl_xor((int)((l1 & low) | (l0 & ~low)), 8, 64);
+                        hw[0][q] = (l0 & low) | (got & ~low);
+                        hw[1][q] = (got & low) | (l1 & ~low);
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < G; ++e) if (rok && c0 + e < N) hv[e] = to_f32(epi.H[(long)row * epi.ldh + c0 + e]);
                 }
             }
-            if constexpr (Epi::NEED >= 2) {
-                if constexpr (VEC) {
-                    if (has_mask) {
 #pragma unroll
-                        for (int e = 0; e < G; ++e) mb[e] = (ops.mk[m * NG + g][e >> 2] >> (8 * (e & 3))) & 0xffu;
-                    }
-                } else if (has_mask) {
+            for (int h = 0; h < 2; ++h) {
+                const int g = 2 * p + h;
+                const int cw = wc * 64 + EC::base(g, lg), c0 = col0 + cw;
+                float hv[G]; unsigned mb[G]; float o[G];
 #pragma unroll
-                    for (int e = 0; e < G; ++e) if (rok && c0 + e < N) mb[e] = epi.mask[(long)row * epi.ldm + c0 + e];
-                }
-            }
-            OT* gp = epi.C + (long)row * epi.ldc + c0;
-            if constexpr (ACCUM) {                               // C += ...: read the old values first
+                for (int e = 0; e < G; ++e) { hv[e] = 0.f; mb[e] = 1u; o[e] = 0.f; }
+                if constexpr (Epi::NEED >= 1) {
+                    if constexpr (VEC) {
 #pragma unroll
-                for (int e = 0; e < G; ++e) if (rok && c0 + e < N) o[e] = to_f32(gp[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < G; ++e) {
-                const int n = EC::tile(g, e), j = e & 3;
-                const bool ok = rok && (c0 + e < N);
-                float v = epi.template compute<ACT>(acc[m][n][j], hv[e], mb[e], cc[e], ok, s1[e], s2[e]);
-                if constexpr (ACCUM) v += o[e];
-                o[e] = (c0 + e < N) ? v : 0.f;
-            }
-            if (epi.stores() && rok && c0 < n_store) {
-                const bool whole = c0 + G <= n_store;
-                if constexpr (sizeof(OT) == 2) {
-                    if (whole && c16) {
-                        const bf16x8 t = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3], (bf16)o[4], (bf16)o[5], (bf16)o[6], (bf16)o[7]};
-                        *(bf16x8*)gp = t;
+                        for (int e = 0; e < G; ++e) {
+                            if constexpr (sizeof(HT) == 2) {
+                                const uint32_t w = hw[h][e >> 1];
+                                hv[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                            } else hv[e] = __uint_as_float(hw[h][e]);
+                        }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < G; ++e) if (c0 + e < n_store) gp[e] = from_f32<OT>(o[e]);
+                        for (int e = 0; e < G; ++e) if (rok && c0 + e < N) hv[e] = to_f32(epi.H[(long)row * epi.ldh + c0 + e]);
+                    }
+                }
+                if constexpr (Epi::NEED >= 2) {
+                    if constexpr (VEC) {
+                        if (has_mask) {
+#pragma unroll
+                            for (int e = 0; e < G; ++e) mb[e] = (ops.mk[m * NG + g][e >> 2] >> (8 * (e & 3))) & 0xffu;
+                        }
+                    } else if (has_mask) {
+#pragma unroll
+                        for (int e = 0; e < G; ++e) if (rok && c0 + e < N) mb[e] = epi.mask[(long)row * epi.ldm + c0 + e];
+                    }
+                }
+                OT* gp = epi.C + (long)row * epi.ldc + c0;
+                if constexpr (ACCUM) {                           // C += ...: read the old values first
+#pragma unroll
+                    for (int e = 0; e < G; ++e) if (rok && c0 + e < N) o[e] = to_f32(gp[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < G; ++e) {
+                    const int n = EC::tile(g, e), j = e & 3;
+                    const bool ok = rok && (c0 + e < N);
+                    const typename Epi::Col cc = epi.col(ecol, BN, cw + e);        // LDS (idle here); kept out of the registers
+                    float v = epi.template compute<ACT>(acc[m][n][j], hv[e], mb[e], cc, ok, s1[h][e], s2[h][e]);
+                    if constexpr (ACCUM) v += o[e];
+                    o[e] = (c0 + e < N) ? v : 0.f;
+                }
+                if constexpr (sizeof(OT) == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t lo = __float_as_uint(to_f32(from_f32<OT>(o[2 * q]))), hi = __float_as_uint(to_f32(from_f32<OT>(o[2 * q + 1])));
+                        pk[h][q] = (lo >> 16) | (hi & 0xffff0000u);
                     }
                 } else {
-                    if (whole && c16) *(f32x4*)gp = f32x4{o[0], o[1], o[2], o[3]};
-                    else if (whole && c8) { ((f32x2*)gp)[0] = f32x2{o[0], o[1]}; ((f32x2*)gp)[1] = f32x2{o[2], o[3]}; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pk[h][q] = __float_as_uint(o[q]);
+                }
+                if (!full_lines && epi.stores() && rok && c0 < n_store) {       // edge tiles, odd leading dimensions, C += ...
+                    const bool whole = c0 + G <= n_store;
+                    if (whole && c16) *(uint4*)gp = uint4{pk[h][0], pk[h][1], pk[h][2], pk[h][3]};
+                    else if (sizeof(OT) == 4 && whole && c8) { ((uint2*)gp)[0] = uint2{pk[h][0], pk[h][1]}; ((uint2*)gp)[1] = uint2{pk[h][2], pk[h][3]}; }
                     else {
 #pragma unroll
                         for (int e = 0; e < G; ++e) if (c0 + e < n_store) gp[e] = from_f32<OT>(o[e]);
                     }
                 }
             }
+            if (full_lines) {
+                // lanes li < 8 give away their second half and get row li+8's first half; lanes li >= 8 the other way round
+                uint32_t st0[4], st1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t send = (pk[1][q] & low) | (pk[0][q] & ~low);
+                    const uint32_t got = (uint32_t)__shfl_xor((int)send, 8, 64);
+                    st0[q] = (pk[0][q] & low) | (got & ~low);        // rows m*16 + (li & 7):     own first half | row li-8's second half
+                    st1[q] = (got & low) | (pk[1][q] & ~low);        // rows m*16 + 8 + (li & 7): row li+8's first half | own second half
+                }
+                const int rbase = row0 + wr * 64 + m * 16 + (li & 7);
+                const int cd = col0 + wc * 64 + EC::base(2 * p + (li >> 3), lg);
+                *(uint4*)(epi.C + (long)rbase * epi.ldc + cd) = uint4{st0[0], st0[1], st0[2], st0[3]};
+                *(uint4*)(epi.C + (long)(rbase + 8) * epi.ldc + cd) = uint4{st1[0], st1[1], st1[2], st1[3]};
+            }
         }
 #ifndef MM_NO_STAT_REDUCE
         if (Epi::STATS && want_stats) {
-            // Column sums of this group over the 16 lanes li of a lane group, per group so that only 2*G partials are live:
-            // reduce-scatter butterfly -- each step a lane keeps the half of its values selected by one bit of li and adds
-            // the partner's copy of that half.  v index = which*G + e; the bits of li, from 8 down, select which, then e.
-            float v[2 * G];
+            // Column sums of each group over the 16 lanes li of a lane group: reduce-scatter butterfly -- each step a lane
+            // keeps the half of its values selected by one bit of li and adds the partner's copy of that half.
+            // v index = which*G + e; the bits of li, from 8 down, select which, then e.
 #pragma unroll
-            for (int e = 0; e < G; ++e) { v[e] = s1[e]; v[G + e] = s2[e]; }
-            int bit = 8;
+            for (int h = 0; h < 2; ++h) {
+                const int cw = wc * 64 + EC::base(2 * p + h, lg);
+                float v[2 * G];
 #pragma unroll
-            for (int half = G; half >= 1; half >>= 1, bit >>= 1) {
-                // bit-select, NOT `up ? v[i + half] : v[i]`: LLVM folds a select of two array elements into one dynamically
-                // indexed access, i.e. a 16-deep v_cmp / v_cndmask chain per value (20 k cycles per tile, measured)
-                const unsigned up = (li & bit) ? 0xffffffffu : 0u;
+                for (int e = 0; e < G; ++e) { v[e] = s1[h][e]; v[G + e] = s2[h][e]; }
+                int bit = 8;
 #pragma unroll
-                for (int i = 0; i < half; ++i) {
-                    const unsigned lo = __float_as_uint(v[i]), hi = __float_as_uint(v[i + half]);
-                    const float keep = __uint_as_float((hi & up) | (lo & ~up));
-                    const float send = __uint_as_float((lo & up) | (hi & ~up));
-                    v[i] = keep + __shfl_xor(send, bit, 64);
+                for (int half = G; half >= 1; half >>= 1, bit >>= 1) {
+                    // bit-select, NOT `up ? v[i + half] : v[i]`: LLVM folds a select of two array elements into one dynamically
+                    // indexed access, i.e. a 16-deep v_cmp / v_cndmask chain per value (20 k cycles per tile, measured)
+                    const unsigned up = (li & bit) ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int i = 0; i < half; ++i) {
+                        const unsigned lo = __float_as_uint(v[i]), hi = __float_as_uint(v[i + half]);
+                        const float keep = __uint_as_float((hi & up) | (lo & ~up));
+                        const float send = __uint_as_float((lo & up) | (hi & ~up));
+                        v[i] = keep + __shfl_xor(send, bit, 64);
+                    }
                 }
+                if constexpr (G == 4) v[0] += __shfl_xor(v[0], 1, 64);      // 8 values, 16 lanes: the last bit is a plain add
+                const int which = li >> 3;
+                const int e = G == 8 ? (li & 7) : ((li >> 1) & 3);
+                if (G == 8 || (li & 1) == 0) red[(wr * 2 + which) * BN + cw + e] = v[0];
             }
-            if constexpr (G == 4) v[0] += __shfl_xor(v[0], 1, 64);      // 8 values, 16 lanes: the last bit is a plain add
-            const int which = li >> 3;
-            const int e = G == 8 ? (li & 7) : ((li >> 1) & 3);
-            if (G == 8 || (li & 1) == 0) red[(wr * 2 + which) * BN + cw + e] = v[0];
         }
 #endif
     }
@@ -337,7 +400,7 @@ __device__ __forceinline__ void nt_epilogue(float* red, const float* ecol, f32x4
     } else if (!vec) {
         nt_epilogue_body<Epi, -1, false, false>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
     } else {
-        nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, lane, wr, wc);
+        nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, BN, lane, wr, wc);
         const int a = epi.act_code();
         if (a == 0) nt_epilogue_body<Epi, 0, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
         else if (a == 1) nt_epilogue_body<Epi, 1, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
