@@ -227,6 +227,25 @@ def main():
                 out["roofline"] = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": MFMA_PEAK_TFLOPS[args.precision],
                                    "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": pmc_traffic(dom["tag"], B),
                                    "kernel": dom["tag"], "launch_ms": dom["ms"], "algorithmic_flops": dom["flops"]}
+            out["roofline"]["definition"] = ("largest single GEMM launch of the step; duration = HIP events on the launch stream around that "
+                                             "launch over the timed steps (eager pass), bytes = algorithmic operand + result bytes of the launch")
+            # the same figure per kernel SYMBOL (what rocprofv3 --stats lists): launches grouped by the template instantiation they select
+            fam = {}
+            for k in kernels:
+                m = summ[k["tag"]]["meta"]
+                if m["kind"] == "nt":
+                    name = (f"gemm_nt<{'f32' if m['a_bytes'] == 4 else 'bf16'} A{'+BN' if m.get('pro') else ''}, "
+                            f"{('store', 'relu-mask', 'bn-bwd')[m['epi']]}, {'f32' if m['c_bytes'] == 4 else 'bf16'} C, {'128x256' if m['N'] % 256 == 0 else '128x128'}>")
+                else:
+                    name = f"gemm_tn<{'f32' if m['p_bytes'] == 4 else 'bf16'} P, {'f32' if m['q_bytes'] == 4 else 'bf16'} Q{'+BN' if m['pro_mask'] else ''}>"
+                f = fam.setdefault(name, dict(symbol=name, launches_per_step=0, ms_per_step=0.0, bytes=0.0, flops=0.0, tags=[]))
+                f["launches_per_step"] += 1; f["ms_per_step"] += k["per_step_ms"]; f["bytes"] += k["bytes"]; f["flops"] += k["flops"]; f["tags"].append(k["tag"])
+            top = max(fam.values(), key=lambda f: f["ms_per_step"])
+            out["roofline_by_symbol"] = {"symbol": top["symbol"], "launches_per_step": top["launches_per_step"], "tags": top["tags"],
+                                         "avg_launch_ms": top["ms_per_step"] / top["launches_per_step"], "bound": "hbm",
+                                         "achieved": top["bytes"] / top["ms_per_step"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": top["bytes"] / top["ms_per_step"] / 1e6 / HBM_PEAK_GBS,
+                                         "TFLOPs": top["flops"] / top["ms_per_step"] / 1e9}
             out["gemm_ms_per_step"] = sum(k["per_step_ms"] for k in kernels)
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items() if k not in ("bytes", "flops")}
                               for kk in kernels[:12]]
