@@ -30,7 +30,7 @@ extern "C" {
 
 enum { MMVAE_F32 = 0, MMVAE_BF16 = 1 };                 /* storage dtype of a buffer   */
 enum { MMVAE_PREC_F32 = 0, MMVAE_PREC_BF16 = 1 };       /* MFMA operand precision      */
-enum { MMVAE_PRO_NONE = 0, MMVAE_PRO_BN_RELU_DROP = 1 };
+enum { MMVAE_PRO_NONE = 0, MMVAE_PRO_BN_RELU_DROP = 1, MMVAE_PRO_BN_BWD_APPLY = 2 };
 enum { MMVAE_EPI_STORE = 0, MMVAE_EPI_RELU_MASK = 1, MMVAE_EPI_BN_BWD = 2 };
 enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 
@@ -110,6 +110,11 @@ typedef struct {
     int32_t nsplit;
     float* slab; int64_t slab_elems;   /* optional workspace: when it holds nsplit*N*K floats the splits store partial tiles there
                                           and a second launch sums them in fixed order (deterministic dW, no atomics); else atomics */
+    /* optional prologue on P (MMVAE_PRO_BN_BWD_APPLY): P = coef0 * (p - coef1 - xhat * coef2), xhat = (p_y - mean) * rstd, i.e.
+       mmvae_bn_bwd_apply folded into the operand load (first layers: nothing else consumes dL/dy).  p_y has p's dtype;
+       p_coef is [3][N] as written by mmvae_bn_bwd_finalize. */
+    int32_t p_prologue;
+    const void* p_y; int64_t ld_py; const float* p_mean; const float* p_rstd; const float* p_coef;
 } mmvae_gemm_tn_args;
 int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
 
@@ -215,6 +220,10 @@ int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const f
 
 /* x *= *scale unless *scale == 1 (loss.backward(gradient=...) support); n elements of dtype. */
 int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const float* scale_dev, void* stream);
+/* the same for up to MMVAE_SCALE_MAX tensors in ONE launch (the records travel in the kernel arguments) */
+#define MMVAE_SCALE_MAX 8
+typedef struct { void* x; int64_t n; int32_t dtype; int32_t pad_; } mmvae_scale_item;
+int mmvae_scale_many(const mmvae_scale_item* items_host, int32_t n_items, const float* scale_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Noise: Philox4x32-10 streams keyed by (seed, offset).  Dropout keep mask (nn.Dropout(0.1),

@@ -219,3 +219,38 @@ def test_nt_wide_tiles(N, K):
         assert float((out2.cpu().double() - ref2).abs().max()) <= _tol(Kp, float(ref2.abs().max()))
     finally:
         lib.mmvae_set_tuning(0, 256 * 128)
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
+@pytest.mark.parametrize("q_kind", ["f32", "act"])
+def test_tn_bn_bwd_apply_prologue(prec, q_kind):
+    """dW GEMM with the BatchNorm-backward correction on its P operand == mmvae_bn_bwd_apply followed by the plain dW GEMM
+    (first layers: reference autograd native_batch_norm_backward + mm, optimize_hyperparameters.py:112)."""
+    M, N, K = 1000, 256, 150
+    g = torch.Generator().manual_seed(11)
+    adt = ops.act_dtype(prec)
+    d = _round(torch.randn(M, N, generator=g), prec)
+    y = _round(torch.randn(M, N, generator=g) * 2 + 0.3, prec)
+    mean, rstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    coef = torch.stack([torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1])
+    Q = torch.randn(M, K, generator=g)
+    Qd = Q.to(DEV) if q_kind == "f32" else _round(Q, prec).to(DEV).to(adt)
+    if q_kind == "act" and prec == PREC_BF16:
+        t = torch.zeros(M, ops.ceil_to(K, 8), dtype=adt, device=DEV); t[:, :K] = Qd; Qd = t
+    Qref = Q if q_kind == "f32" and prec == PREC_F32 else _round(Q, prec)
+    xh = (y.double() - mean.double()) * rstd.double()
+    dy = coef[0].double() * (d.double() - coef[1].double() - xh * coef[2].double())
+    dyq = _round(dy.float(), prec).double()                       # the operand is rounded to the compute type once
+    ref, refb = dyq.t() @ Qref.double(), dyq.sum(0)
+    dd, yd = d.to(DEV).to(adt), y.to(DEV).to(adt)
+    dw = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV)
+    ops.gemm_tn(prec, dd, Qd, dw, db, N, K, p_prologue=(yd, mean.to(DEV), rstd.to(DEV), coef.to(DEV).contiguous()))
+    tol = (2e-5 if prec == PREC_F32 else 3e-3) * np.sqrt(M) * float(ref.abs().max())     # bf16: an operand rounding may flip
+    assert float((dw.cpu().double() - ref).abs().max()) <= tol
+    assert float((db.cpu().double() - refb).abs().max()) <= (2e-5 if prec == PREC_F32 else 3e-3) * np.sqrt(M) * float(refb.abs().max()) + 1e-3
+    # and against the two-launch form it replaces
+    d2 = dd.clone()
+    ops.bn_bwd_apply(d2, yd, N, mean.to(DEV), rstd.to(DEV), coef.to(DEV).contiguous())
+    dw2 = torch.zeros(N, K, device=DEV); db2 = torch.zeros(N, device=DEV)
+    ops.gemm_tn(prec, d2, Qd, dw2, db2, N, K)
+    assert float((dw - dw2).abs().max()) <= 1e-3 * float(dw2.abs().max())

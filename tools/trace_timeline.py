@@ -4,7 +4,8 @@ import csv, glob, re, sys, collections
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name']]
-a, b = idx[-3] + 1, idx[-2] + 1
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -3
+a, b = idx[which] + 1, idx[which + 1] + 1
 step = rows[a:b + 1]
 t0 = int(step[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in step)
 iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in step)

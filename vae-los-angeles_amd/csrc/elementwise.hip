@@ -392,7 +392,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 8; }
+extern "C" int mmvae_abi_version(void) { return 9; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -527,6 +527,36 @@ extern "C" int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t l
     const int grid = grid_for((long)M * N);
     if (out_dtype == MMVAE_BF16) hipLaunchKernelGGL(sigmoid_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, g, ldg, p, ldpp, (bf16*)out, ldo);
     else hipLaunchKernelGGL(sigmoid_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, g, ldg, p, ldpp, (float*)out, ldo);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+struct ScaleBatch { mmvae_scale_item it[MMVAE_SCALE_MAX]; int count; };
+__global__ __launch_bounds__(256) void scale_many_kernel(ScaleBatch b, const float* scale) {
+    const float s = *scale;
+    if (s == 1.f) return;
+    for (int k = 0; k < b.count; ++k) {
+        const long n = b.it[k].n;
+        if (b.it[k].dtype == MMVAE_BF16) {
+            bf16* x = (bf16*)b.it[k].x;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = from_f32<bf16>(to_f32(x[i]) * s);
+        } else {
+            float* x = (float*)b.it[k].x;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= s;
+        }
+    }
+}
+
+extern "C" int mmvae_scale_many(const mmvae_scale_item* items, int32_t n_items, const float* scale_dev, void* stream) {
+    if (!items || n_items <= 0 || n_items > MMVAE_SCALE_MAX || !scale_dev) return MMVAE_ERR_ARG;
+    ScaleBatch b; b.count = n_items;
+    long nmax = 0;
+    for (int k = 0; k < n_items; ++k) {
+        if (!items[k].x || items[k].n <= 0 || (items[k].dtype != MMVAE_BF16 && items[k].dtype != MMVAE_F32)) return MMVAE_ERR_ARG;
+        b.it[k] = items[k];
+        if (items[k].n > nmax) nmax = items[k].n;
+    }
+    hipLaunchKernelGGL(scale_many_kernel, dim3(grid_for(nmax)), dim3(256), 0, (hipStream_t)stream, b, scale_dev);
     MM_CHECK_LAUNCH();
     return 0;
 }

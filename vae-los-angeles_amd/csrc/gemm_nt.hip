@@ -79,7 +79,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     const int wr = wid / WN, wc = wid % WN;
 
     nt_epilogue_fill_cols<Epi, WN>(ecol, epi, col0, N, tid);       // visible after the first barrier below
-    if (Src::NEEDS_AUX) { src.init(aux, tid); __syncthreads(); }
+    if (Src::NEEDS_AUX) { src.init(aux, tid, 0); __syncthreads(); }
 
     f32x4 acc[4][4];
 #pragma unroll

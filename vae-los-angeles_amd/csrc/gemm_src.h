@@ -36,7 +36,7 @@ struct SrcPlain {
     static constexpr bool NEEDS_AUX = false;
     const AT* p; long lda; int M, K;
     typedef RawVec<AT, EPC> Raw;
-    __device__ __forceinline__ void init(float*, int) const {}
+    __device__ __forceinline__ void init(float*, int, int) const {}
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {
         // 32-bit element offsets (the entry points reject operands of 4 GiB or more): the loads take the
         // scalar-base + 32-bit-VGPR-offset form, one address VGPR per load instead of a 64-bit pair
@@ -74,7 +74,7 @@ struct SrcBnReluDrop {
     const float* scale; const float* shift;
     const uint8_t* mask; long ldm; float inv_keep;
     struct Raw { RawVec<CT, EPC> y; uint32_t m[EPC / 4]; };
-    __device__ __forceinline__ void init(float* aux, int tid) const {
+    __device__ __forceinline__ void init(float* aux, int tid, int) const {
         for (int i = tid; i < K; i += NTHREADS) { aux[i] = scale[i]; aux[512 + i] = shift[i]; }
     }
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {        // K % EPC == 0 (hidden widths)
@@ -102,6 +102,48 @@ struct SrcBnReluDrop {
             float v = fmaxf(r.y.get(i) * sc + sh, 0.f);
             float keep = ((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu) ? inv_keep : 0.f;
             o.set(i, v * keep);
+        }
+    }
+};
+
+// P = c0 * (d - c1 - xhat * c2), xhat = (y - mean) * rstd: the BatchNorm-backward correction (mmvae_bn_bwd_apply) applied on
+// the operand load of the dW GEMM.  For a FIRST layer nothing else consumes dL/dy, so the element-wise pass over d (read d, y,
+// write d: 3 x 67 MB on the critical path of the step) disappears; d stays the raw epilogue output of the dX contraction.
+// Per-column constants of the workgroup's 128-column tile sit in LDS (aux: 5 x 128 floats, index = column & 127).
+template <typename CT>
+struct SrcBnBwdApply {
+    static constexpr int EPC = Mma<CT>::EPC;
+    static constexpr bool NEEDS_AUX = true;
+    const CT* d; long ldd; const CT* y; long ldy; int M, K;          // K = number of columns (the layer width)
+    const float* mean; const float* rstd; const float* coef;          // coef: [3][K]
+    struct Raw { RawVec<CT, EPC> d, y; };
+    __device__ __forceinline__ void init(float* aux, int tid, int col0) const {
+        if (tid < TILE) {
+            const int c = col0 + tid;
+            const bool ok = c < K;
+            aux[tid] = ok ? mean[c] : 0.f; aux[TILE + tid] = ok ? rstd[c] : 0.f;
+            aux[2 * TILE + tid] = ok ? coef[c] : 0.f; aux[3 * TILE + tid] = ok ? coef[K + c] : 0.f; aux[4 * TILE + tid] = ok ? coef[2 * K + c] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {          // K % EPC == 0 (hidden widths), rows padded
+        const unsigned rc = (unsigned)min(row, M - 1), kc = (unsigned)min(k, K - EPC);
+        if constexpr (sizeof(CT) == 2) {
+            r.d.v = *(const bf16x8*)(d + (rc * (unsigned)ldd + kc));
+            r.y.v = *(const bf16x8*)(y + (rc * (unsigned)ldy + kc));
+        } else {
+            const f32x4 a = *(const f32x4*)(d + (rc * (unsigned)ldd + kc)), b = *(const f32x4*)(y + (rc * (unsigned)ldy + kc));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { r.d.v[i] = a[i]; r.y.v[i] = b[i]; }
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const {
+        const bool ok = row < M && k < K;
+        const int c = k & (TILE - 1);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) {
+            const float xh = (r.y.get(i) - aux[c + i]) * aux[TILE + c + i];
+            const float v = aux[2 * TILE + c + i] * (r.d.get(i) - aux[3 * TILE + c + i] - xh * aux[4 * TILE + c + i]);
+            o.set(i, ok ? v : 0.f);
         }
     }
 };

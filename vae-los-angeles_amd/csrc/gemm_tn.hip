@@ -81,7 +81,8 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     typedef typename Mma<CT>::frag frag;
     constexpr int BUF = 2 * G::MT * G::ROWB;                 // one batch step: P tile + Q tile (32 KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
-    float* aux = (float*)(smem + 2 * BUF);
+    float* aux = (float*)(smem + 2 * BUF);                   // Q prologue: BN scale / shift
+    float* auxp = aux + 1024;                                // P prologue: BN-backward constants of this tile's 128 columns
 
     const int L = blockIdx.x, slot = L >> 3;
     const int tile = slot % ntiles;
@@ -96,7 +97,9 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
-    if (QSrc::NEEDS_AUX) { qs.init(aux, tid); __syncthreads(); }
+    if (QSrc::NEEDS_AUX) qs.init(aux, tid, k0);
+    if (PSrc::NEEDS_AUX) ps.init(auxp, tid, n0);
+    if (QSrc::NEEDS_AUX || PSrc::NEEDS_AUX) __syncthreads();
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -132,7 +135,7 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             int m = m_begin + t * G::MT + r;
             m = m >= m_end ? M : m;
             Chunk<CT> o;
-            ps.finish(rp[i], m, n0 + ch * EPC, o, aux);
+            ps.finish(rp[i], m, n0 + ch * EPC, o, auxp);
             *(decltype(o.v)*)(sP + G::chunk_off(r, ch)) = o.v;
             qs.finish(rq[i], m, k0 + ch * EPC, o, aux);
             *(decltype(o.v)*)(sQ + G::chunk_off(r, ch)) = o.v;
@@ -336,7 +339,7 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
     float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
-    constexpr int LDS = 4 * G::MT * G::ROWB + 4096;
+    constexpr int LDS = 4 * G::MT * G::ROWB + 4096 + 4096;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -376,6 +379,16 @@ static int tn_dispatch_q(const mmvae_gemm_tn_args* a, const PSrc& ps, hipStream_
 
 template <typename CT>
 static int tn_dispatch_p(const mmvae_gemm_tn_args* a, hipStream_t st) {
+    constexpr int EPC = Mma<CT>::EPC;
+    if (a->p_prologue == MMVAE_PRO_BN_BWD_APPLY) {
+        if ((a->p_dtype == MMVAE_BF16) != (sizeof(CT) == 2)) return MMVAE_ERR_DTYPE;
+        if (!a->p_y || !a->p_mean || !a->p_rstd || !a->p_coef || a->N % EPC || a->ldp % EPC || a->ld_py % EPC ||
+            ((uintptr_t)a->p & 15) || ((uintptr_t)a->p_y & 15)) return MMVAE_ERR_ARG;
+        if ((long)a->M * a->ld_py * (long)sizeof(CT) >= (1L << 32)) return MMVAE_ERR_ARG;
+        SrcBnBwdApply<CT> p{(const CT*)a->p, a->ldp, (const CT*)a->p_y, a->ld_py, a->M, a->N, a->p_mean, a->p_rstd, a->p_coef};
+        return tn_dispatch_q<CT>(a, p, st);
+    }
+    if (a->p_prologue != MMVAE_PRO_NONE) return MMVAE_ERR_ARG;
     if (a->p_dtype == MMVAE_BF16) {
         if constexpr (sizeof(CT) == 2) {
             if (a->ldp % 8 || ((uintptr_t)a->p & 15)) return MMVAE_ERR_ARG;

@@ -9,11 +9,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
-PRO_NONE, PRO_BN_RELU_DROP = 0, 1
+PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY = 0, 1, 2
 EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TILE = 128
@@ -49,7 +49,12 @@ class GemmTnArgs(C.Structure):
                 ("q_prologue", i32),
                 ("pro_scale", vp), ("pro_shift", vp), ("pro_mask", vp), ("ld_pro_mask", i64), ("pro_inv_keep", f32),
                 ("dw", vp), ("lddw", i64), ("db", vp),
-                ("nsplit", i32), ("slab", vp), ("slab_elems", i64)]
+                ("nsplit", i32), ("slab", vp), ("slab_elems", i64),
+                ("p_prologue", i32), ("p_y", vp), ("ld_py", i64), ("p_mean", vp), ("p_rstd", vp), ("p_coef", vp)]
+
+
+class ScaleItem(C.Structure):
+    _fields_ = [("x", vp), ("n", i64), ("dtype", i32), ("pad_", i32)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -116,6 +121,7 @@ _SIGNATURES = {
     "mmvae_loss_finalize": [vp, f32, f32, vp, vp],
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
+    "mmvae_scale_many": [C.POINTER(ScaleItem), i32, vp, vp],
     "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, vp],
     "mmvae_counter_add": [vp, C.c_uint64, vp],
     "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp],

@@ -20,6 +20,7 @@ from .ops import (PREC_BF16, PREC_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, EPI_RELU
 _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
 _BN_BWD_RECOMPUTE = os.environ.get("MMVAE_BN_BWD_RECOMPUTE", "0") == "1"
+_FUSE_BN_APPLY = os.environ.get("MMVAE_FUSE_BN_APPLY", "1") == "1"       # A/B switch: BN-backward correction of first layers inside the dW GEMM
 
 
 def set_default_precision(name):
@@ -125,8 +126,8 @@ _ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.uint8: 1, torch.int64: 8}
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def _side_stream(device, which=0):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _SIDE_STREAMS.get(key)
     if st is None:
         st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -179,9 +180,11 @@ class EncoderMLP:
     def widths(self):
         return [l.out_features for l in self.linears]
 
-    def forward(self, prec, x, train, masks, stats_bufs=None):
+    def forward(self, prec, x, train, masks, stats_bufs=None, masks_ready=None):
         """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval).
-        stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer."""
+        stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer.
+        masks_ready: optional (stream, event): the masks are being written on another stream; the first launch that reads
+        one (the SECOND GEMM: a mask is applied on the consumer's operand load) waits for the event."""
         B, dev = x.shape[0], x.device
         adt = act_dtype(prec)
         saved = []
@@ -189,6 +192,9 @@ class EncoderMLP:
         nt = (B + TILE - 1) // TILE
         for lin, bn, pl in zip(self.linears, self.bns, self.pl):
             N, K = pl.N, pl.K
+            if masks_ready is not None and pro is not None:
+                masks_ready[0].wait_event(masks_ready[1])
+                masks_ready = None
             y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
             st = BNState(N, dev)
             if train:
@@ -206,6 +212,8 @@ class EncoderMLP:
             saved.append((h, pro, y, st, new_pro))
             h, pro = y, new_pro
         heads = torch.empty(B, 2 * self.latent, dtype=torch.float32, device=dev)
+        if masks_ready is not None and pro is not None:
+            masks_ready[0].wait_event(masks_ready[1])
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
@@ -240,6 +248,11 @@ class EncoderMLP:
             else:
                 ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
                 ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+                if i == 0 and _FUSE_BN_APPLY:
+                    # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
+                    tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
+                       p_prologue=(y, st.mean, st.rstd, coef), tag=f"{self.name}.L{i}.dW")
+                    continue
                 ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
             tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
             src, src_wt, src_n, src_k = d, pl.wt, K, N
@@ -389,29 +402,46 @@ class VAEGraph:
         Ld = self.latent
         widths_a = self.enc_a.widths() if (train and xa is not None) else []
         widths_b = self.enc_b.widths() if (train and xb is not None) else []
-        masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
-        st_all = [t.view(2, -1) for t in zeros_pack(dev, [(2 * w, torch.float64) for w in widths_a + widths_b])] if train else []
-        # independent chains run on two HIP streams (parallel branches under hipGraph capture): EncoderA beside EncoderB,
-        # the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
+        # independent chains run on HIP streams of their own (parallel branches under hipGraph capture): the noise launch
+        # beside the first-layer GEMMs (nothing reads a mask before the second GEMM, eps before the fusion), EncoderA beside
+        # EncoderB, the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if (self.overlap_dw and xa is not None and xb is not None) else None
+        nside = _side_stream(dev, 1) if (side is not None and self.noise._injected is None) else None
+        noise_ev = None
+        if nside is not None:
+            _fork(main, nside)
+            with torch.cuda.stream(nside), ops.pinned_stream(nside):
+                masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)
+                for t in masks + [eps]:
+                    t.record_stream(main)
+                    t.record_stream(side)
+                noise_ev = torch.cuda.Event()
+                noise_ev.record(nside)
+        else:
+            masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
+        st_all = [t.view(2, -1) for t in zeros_pack(dev, [(2 * w, torch.float64) for w in widths_a + widths_b])] if train else []
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
             if side is not None:
                 _fork(main, side)
             with ops.pinned_stream(side if side is not None else main):
                 heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
-                                                             st_all[:len(widths_a)] if train else None)
+                                                             st_all[:len(widths_a)] if train else None,
+                                                             masks_ready=(side, noise_ev) if (noise_ev is not None and side is not None) else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
             heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
-                                                         st_all[len(widths_a):] if train else None)
+                                                         st_all[len(widths_a):] if train else None,
+                                                         masks_ready=(main, noise_ev) if noise_ev is not None else None)
         if site is not None:
             if site.dtype != torch.int64:
                 site = site.long()
             site = site.contiguous()
             table = self.enc_c.table()
             saved["site"] = site
+        if noise_ev is not None:
+            main.wait_event(noise_ev)                  # join (eps; also closes the branch when no encoder waited)
         if side is not None:
             _fork(side, main)                          # join: the fusion kernel needs EncoderA's heads
         mu = torch.empty(B, Ld, dtype=torch.float32, device=dev)
@@ -483,6 +513,7 @@ class VAEGraph:
                 ev.record(main)
                 side.wait_event(ev)
                 keep.extend((p, q))                       # operands stay alive until the join below
+                keep.extend(kw.get("p_prologue") or ())
                 with ops.pinned_stream(side):
                     ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         first = True

@@ -41,17 +41,16 @@ class VAEGraphFn(torch.autograd.Function):
         stash = saved.get("loss_grads")
         if stash is not None and stash.get("scale") is not None:
             scale = stash["scale"]
+            ops.scale_many(list(stash["g_outs"]) + [stash["g_mu"], stash["g_lv"]], scale)       # one launch, not five
             for i in range(n_out):
                 sg = stash["g_outs"][i]
                 if sg is None:
                     continue
-                ops.scale_if_needed(sg, scale)
                 if g_outs[i] is not None:            # rare: another loss term also touched this output
                     sg[:, :g_outs[i].shape[1]] += _to_stash_space(g_outs[i], saved["dec"][i][1], graph.decoders[i], sg.dtype)
                 g_outs[i], flags[i] = sg, graph.decoders[i].final_sigmoid
             for key, cur in (("g_mu", g_mu), ("g_lv", g_lv)):
                 sg = stash[key]
-                ops.scale_if_needed(sg, scale)
                 if cur is not None:
                     sg += cur
             g_mu, g_lv = stash["g_mu"], stash["g_lv"]

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import (F32, BF16, PREC_F32, PREC_BF16, PRO_NONE, PRO_BN_RELU_DROP, EPI_STORE, EPI_RELU_MASK,
+from ._lib import (F32, BF16, PREC_F32, PREC_BF16, PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY, EPI_STORE, EPI_RELU_MASK,
                    EPI_BN_BWD, ACT_NONE, ACT_RELU, ACT_SIGMOID, TILE)
 
 DROP_P = 0.1                      # nn.Dropout(0.1), reference src/models/encoders.py:16,34,38
@@ -217,8 +217,9 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
     return out
 
 
-def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, slab=None, tag=None):
-    """dw[N,K] += p[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(p).  dw/db fp32, pre-zeroed."""
+def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, p_prologue=None, nsplit=0, slab=None, tag=None):
+    """dw[N,K] += pro_p(p)[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(pro_p(p)).  dw/db fp32, pre-zeroed.
+    p_prologue = (y, mean, rstd, coef): the BatchNorm-backward correction of mmvae_bn_bwd_apply applied on the load of p."""
     _mat(p, "p"); _mat(q, "q")
     g = L.GemmTnArgs()
     g.prec, g.M, g.N, g.K = prec, p.shape[0], N, K
@@ -230,6 +231,12 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, slab=None, t
         g.pro_scale, g.pro_shift, g.pro_mask = sc.data_ptr(), sh.data_ptr(), _p(mask)
         g.ld_pro_mask = _ld(mask) if mask is not None else 0
         g.pro_inv_keep = inv_keep
+    if p_prologue is not None:
+        py, mean, rstd, coef = p_prologue
+        _mat(py, "p_y")
+        assert py.dtype == p.dtype and coef.shape[0] == 3 and coef.shape[1] == N and coef.is_contiguous()
+        g.p_prologue = PRO_BN_BWD_APPLY
+        g.p_y, g.ld_py, g.p_mean, g.p_rstd, g.p_coef = py.data_ptr(), _ld(py), mean.data_ptr(), rstd.data_ptr(), coef.data_ptr()
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     g.dw, g.lddw, g.db = dw.data_ptr(), K, _p(db)
     g.nsplit = nsplit
@@ -238,8 +245,8 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, nsplit=0, slab=None, t
     t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_tn(C.byref(g), _stream()), "mmvae_gemm_tn")
     if t0 is not None:
-        PROBE.end(tag, t0, dict(kind="tn", M=p.shape[0], N=N, K=K, p_bytes=p.element_size(), q_bytes=q.element_size(),
-                                pro_mask=q_prologue is not None and q_prologue[2] is not None))
+        PROBE.end(tag, t0, dict(kind="tn", M=p.shape[0], N=N, K=K, p_bytes=p.element_size() * (2 if p_prologue is not None else 1),
+                                q_bytes=q.element_size(), pro_mask=q_prologue is not None and q_prologue[2] is not None))
 
 
 # --------------------------------------------------------------------------------------------
@@ -337,6 +344,15 @@ def loss_finalize(sums, beta, gamma, out4):
 def sigmoid_bwd(g, p, out):
     L.check(L.load().mmvae_sigmoid_bwd(g.shape[0], g.shape[1], g.data_ptr(), _ld(g), p.data_ptr(), _ld(p), out.data_ptr(),
                                        _dt(out), _ld(out), _stream()), "mmvae_sigmoid_bwd")
+
+
+def scale_many(tensors, scale):
+    """x *= *scale (device scalar) unless it is 1, for every tensor of the list, in one launch per 8 tensors."""
+    ts = [t for t in tensors if t is not None]
+    for i in range(0, len(ts), 8):
+        chunk = ts[i:i + 8]
+        items = (L.ScaleItem * len(chunk))(*[L.ScaleItem(t.data_ptr(), t.numel(), _dt(t), 0) for t in chunk])
+        L.check(L.load().mmvae_scale_many(items, len(chunk), scale.data_ptr(), _stream()), "mmvae_scale_many")
 
 
 def scale_if_needed(x, scale):
