@@ -86,6 +86,63 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
     if (sink == 12345.678f) out[blockIdx.x * 256 + tid] = sink;
 }
 
+// Variant 5/6: the TN (dW) kernel's inner step: operands by ds_read_b64_tr_b16 (two per 16x16x32 fragment) from a
+// [64 m][256 B] tile pair, 32 transpose reads + 32 MFMAs per wave and step.  WPS = workgroups per CU (2 -> 2 waves/SIMD, 4 -> 4).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void ktr(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    for (int i = tid; i < 2 * 16384 / 4; i += 256) ((unsigned*)smem)[i] = 0x3c003c00u + (i & 7);
+    __syncthreads();
+    f32x4 acc[4][4];
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto frag = [&](const unsigned char* tile, int colbase, int s) {
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int r = s * 32 + 8 * g + q, c32 = colbase >> 4;
+        const int f = (r & 3) | (((r >> 3) & 1) << 2);
+        const int off0 = r * 256 + ((c32 ^ f) << 5) + (p << 3);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off0 + 1024));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u; u.s.a = lo; u.s.b = hi;
+        return u.v;
+    };
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = frag(smem, wr * 64 + m * 16, s);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = frag(smem + 16384, wc * 64 + n * 16, s);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    float sink = 0.f;
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) sink += acc[m][n][0] + acc[m][n][3];
+    if (sink == 12345.678f) out[blockIdx.x * 256 + tid] = sink;
+}
+
+template <int WPS>
+static void run_tr(const char* name, float* out, int iters, double ghz) {
+    const int blocks = 256 * WPS * 4;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    ktr<WPS><<<blocks, 256>>>(out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    ktr<WPS><<<blocks, 256>>>(out, iters);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    const double us_per_step = ms * 1e3 / ((double)blocks / 256 * iters);
+    printf("%-24s %8.3f ms  %7.1f ns / tile-step / CU  (%6.0f cycles @ %.1f GHz)  %7.1f TFLOP/s-equivalent\n", name, ms, us_per_step * 1e3,
+           us_per_step * 1e3 * ghz, ghz, 2.0 * 128 * 128 * 64 * blocks * iters / (ms * 1e-3) / 1e12);
+}
+
 template <int V>
 static void run(const char* name, float* out, int iters, double ghz) {
     const int blocks = 256 * 2 * 4;                 // 4 rounds of 2 workgroups per CU
@@ -105,7 +162,7 @@ static void run(const char* name, float* out, int iters, double ghz) {
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
-    float* out; hipMalloc(&out, 256 * 2 * 4 * 256 * 4);
+    float* out; hipMalloc(&out, 256 * 4 * 4 * 256 * 4);
     int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
     const double ghz = clk / 1e6;
     printf("device clock %.2f GHz, %d iterations per workgroup\n", ghz, iters);
@@ -114,5 +171,7 @@ int main(int argc, char** argv) {
     run<1>("lds b128 reads only", out, iters, ghz);
     run<2>("lds + mfma16x16x32", out, iters, ghz);
     run<3>("lds + mfma32x32x16", out, iters, ghz);
+    run_tr<2>("tr_b64 + mfma, 2 wg/CU", out, iters, ghz);
+    run_tr<4>("tr_b64 + mfma, 4 wg/CU", out, iters, ghz);
     return 0;
 }

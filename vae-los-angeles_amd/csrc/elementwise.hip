@@ -189,23 +189,51 @@ __device__ __forceinline__ void store_vec(GT* p, const float* v) {
     else for (int e = 0; e < V; ++e) p[e] = o[e];
 }
 
+// Flat index i = r * vpr + cv walks the [B][A/V] vector grid with a grid stride; (r, cv) are advanced incrementally -- an
+// integer division per vector made these parts VALU-bound (~40 lane-ops per 8 bytes), not HBM-bound.
+struct RowWalk {
+    unsigned r, cv, dr, dc, vpr;
+    __device__ __forceinline__ RowWalk(unsigned i0, unsigned stride, unsigned vpr_) : vpr(vpr_) {
+        r = i0 / vpr; cv = i0 - r * vpr; dr = stride / vpr; dc = stride - dr * vpr;
+    }
+    __device__ __forceinline__ void next() { r += dr; cv += dc; if (cv >= vpr) { cv -= vpr; ++r; } }
+};
+
+// U vectors per thread are loaded BEFORE any is processed: the stores of one iteration may alias the loads of the next as far
+// as the compiler knows, so a one-vector loop keeps only two loads in flight per thread -- 8 MB chip-wide, which at ~2 us
+// of loaded latency is the 3.7 TB/s this kernel was stuck at.
+constexpr int LOSS_U = 4;
+
 template <typename GT, int V>
 __device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, long stride) {
     float acc = 0.f;
     const int vpr = a.A / V;
     const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
-    for (unsigned i = (unsigned)tid0; i < total; i += (unsigned)stride) {
-        const unsigned r = i / (unsigned)vpr, c = (i - r * (unsigned)vpr) * V;
-        float x[V], t[V], g[V];
-        VLoad<float, V>::ld(a.recon_a + (long)r * a.ld_ra + c, x);
-        VLoad<float, V>::ld(a.a + (long)r * a.ld_a + c, t);
+    RowWalk w((unsigned)tid0, (unsigned)stride, (unsigned)vpr);
+    for (unsigned i = (unsigned)tid0; i < total; i += LOSS_U * (unsigned)stride) {
+        float x[LOSS_U][V], t[LOSS_U][V];
+        unsigned rr[LOSS_U], cc[LOSS_U];
+        bool ok[LOSS_U];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { const float d = x[e] - t[e]; acc += d * d; g[e] = 2.f * d; }
-        if (a.g_a) {
-            GT* gp = (GT*)a.g_a + (long)r * a.ld_ga;
-            store_vec<GT, V>(gp + c, g);
-            if ((int)c + V >= a.A)                       // last vector of the row: zero the pad columns (GEMM operand contract)
-                for (int e = a.A; e < (int)a.ld_ga && e < ((a.A + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+        for (int u = 0; u < LOSS_U; ++u) {
+            ok[u] = i + u * (unsigned)stride < total && i + u * (unsigned)stride >= i;
+            rr[u] = ok[u] ? w.r : 0u; cc[u] = ok[u] ? w.cv * V : 0u;          // clamped: the loads always issue
+            VLoad<float, V>::ld(a.recon_a + (long)rr[u] * a.ld_ra + cc[u], x[u]);
+            VLoad<float, V>::ld(a.a + (long)rr[u] * a.ld_a + cc[u], t[u]);
+            w.next();
+        }
+#pragma unroll
+        for (int u = 0; u < LOSS_U; ++u) {
+            if (!ok[u]) continue;
+            float g[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const float d = x[u][e] - t[u][e]; acc += d * d; g[e] = 2.f * d; }
+            if (a.g_a) {
+                GT* gp = (GT*)a.g_a + (long)rr[u] * a.ld_ga;
+                store_vec<GT, V>(gp + cc[u], g);
+                if ((int)cc[u] + V >= a.A)                   // last vector of the row: zero the pad columns (GEMM operand contract)
+                    for (int e = a.A; e < (int)a.ld_ga && e < ((a.A + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+            }
         }
     }
     return acc;
@@ -216,24 +244,39 @@ __device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, l
     float acc = 0.f;
     const int vpr = a.D / V;
     const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
-    for (unsigned i = (unsigned)tid0; i < total; i += (unsigned)stride) {
-        const unsigned r = i / (unsigned)vpr, c = (i - r * (unsigned)vpr) * V;
-        float p[V], t[V], g[V];
-        VLoad<float, V>::ld(a.recon_b + (long)r * a.ld_rb + c, p);
-        VLoad<float, V>::ld(a.b + (long)r * a.ld_b + c, t);
+    RowWalk w((unsigned)tid0, (unsigned)stride, (unsigned)vpr);
+    for (unsigned i = (unsigned)tid0; i < total; i += LOSS_U * (unsigned)stride) {
+        float p[LOSS_U][V], t[LOSS_U][V];
+        unsigned rr[LOSS_U], cc[LOSS_U];
+        bool ok[LOSS_U];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float lp = fmaxf(__logf(p[e]), -100.f), l1p = fmaxf(__logf(1.f - p[e]), -100.f);   // v_log_f32: 1 ulp, clamp as torch
-            acc -= t[e] * lp + (1.f - t[e]) * l1p;
-            const float pq = (1.f - p[e]) * p[e];
-            g[e] = (p[e] - t[e]) / fmaxf(pq, 1e-12f);
-            if (a.grad_b_wrt_logit) g[e] *= pq;
+        for (int u = 0; u < LOSS_U; ++u) {
+            ok[u] = i + u * (unsigned)stride < total && i + u * (unsigned)stride >= i;
+            rr[u] = ok[u] ? w.r : 0u; cc[u] = ok[u] ? w.cv * V : 0u;
+            VLoad<float, V>::ld(a.recon_b + (long)rr[u] * a.ld_rb + cc[u], p[u]);
+            VLoad<float, V>::ld(a.b + (long)rr[u] * a.ld_b + cc[u], t[u]);
+            w.next();
         }
-        if (a.g_b) {
-            GT* gp = (GT*)a.g_b + (long)r * a.ld_gb;
-            store_vec<GT, V>(gp + c, g);
-            if ((int)c + V >= a.D)
-                for (int e = a.D; e < (int)a.ld_gb && e < ((a.D + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+#pragma unroll
+        for (int u = 0; u < LOSS_U; ++u) {
+            if (!ok[u]) continue;
+            float g[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float pe = p[u][e], te = t[u][e];
+                const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
+                acc -= te * lp + (1.f - te) * l1p;
+                const float pq = (1.f - pe) * pe, d = pe - te;
+                // torch: grad_p = (p - t) / max(p (1 - p), 1e-12); w.r.t. the logit that times p (1 - p): exactly (p - t) unless clamped
+                if (a.grad_b_wrt_logit) g[e] = pq >= 1e-12f ? d : d * pq * 1e12f;
+                else g[e] = d * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f));
+            }
+            if (a.g_b) {
+                GT* gp = (GT*)a.g_b + (long)rr[u] * a.ld_gb;
+                store_vec<GT, V>(gp + cc[u], g);
+                if ((int)cc[u] + V >= a.D)
+                    for (int e = a.D; e < (int)a.ld_gb && e < ((a.D + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
+            }
         }
     }
     return acc;

@@ -147,6 +147,11 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     //   into the registers just staged | reads (kt+1, s0) -> f0 | MFMA f1
     // Before the barrier every wave has drained its LDS traffic (lgkmcnt(0)), so nobody still reads the buffer the next
     // step overwrites; after it the freshly staged tile is visible.
+    // Memory instructions are SPREAD between the MFMAs (2 MFMA, 1 ds_write ... in the first half; 2 MFMA, 1 global load ...
+    // in the second) instead of issued as two bursts: a burst of 8 wave-wide loads fills the CU's texture-address queue
+    // (64 B/clk: 128 cycles for the burst), the wave blocks at issue and its MFMAs wait behind it.  tools/ubench_stage.hip:
+    // 1256 -> 999 cycles per 128x128x64 step and CU for this loop skeleton (no-traffic floor 700, MFMA floor 560).
+    constexpr int NMEM = A_PER + 4;                          // loads / LDS writes per lane and K step
     auto kstep = [&](auto& ra_n, auto& rb_n, int kt, int buf, bool has_next, bool do_fetch, int fetch_kt) {
         MM_T(t0);
         rd(f1a, f1b, buf, 1);
@@ -158,6 +163,10 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         MM_ACC(5, t1b - t1);
 #endif
         if (has_next) stage(ra_n, rb_n, kt + 1, buf ^ 1);
+#ifndef MM_STAMP
+#pragma unroll
+        for (int j = 0; j < NMEM; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 16 / NMEM, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#endif
 #ifdef MM_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -167,6 +176,10 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         if (do_fetch) fetch(ra_n, rb_n, fetch_kt);
         if (has_next) rd(f0a, f0b, buf ^ 1, 0);
         mma(f1a, f1b);
+#ifndef MM_STAMP
+#pragma unroll
+        for (int j = 0; j < NMEM; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 16 / NMEM, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#endif
         MM_T(t4);
 #ifdef MM_STAMP
         if (st_acc[4] == 0) t_first = t0;

@@ -169,6 +169,7 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, t_first = 0, t_last = 0, st_acc5 = 0;
     MT_T(t_begin);
 #endif
+    // registers -> LDS writes and the global loads are spread between the MFMAs of the two fragment steps (see gemm_nt.hip)
     auto kstep = [&](auto& rp_n, auto& rq_n, int t, int buf, bool has_next, bool do_fetch, int fetch_t) {
         MT_T(t0);
         compute(buf, 0);
@@ -179,9 +180,17 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
         st_acc5 += t1b - t1;
 #endif
         if (has_next) stage(rp_n, rq_n, t + 1, buf ^ 1);
+#ifndef MM_STAMP
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#endif
         MT_T(t2);
         compute(buf, 1);
-        if (do_fetch) fetch(rp_n, rq_n, fetch_t);
+        if (do_fetch) fetch(rp_n, rq_n, fetch_t);               // into the registers just staged
+#ifndef MM_STAMP
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#endif
 #ifdef MM_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -205,8 +214,8 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
         for (int t = 0; t < nt; ++t) {
             compute(t & 1, 0);
             if (t + 1 < nt) stage(rp0, rq0, t + 1, (t + 1) & 1);
+            if (t + 2 < nt) fetch(rp0, rq0, t + 2);               // one set: issue the next loads the moment the registers are free
             compute(t & 1, 1);
-            if (t + 2 < nt) fetch(rp0, rq0, t + 2);
             __syncthreads();
         }
     } else if (nt >= 5) {
