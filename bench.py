@@ -109,8 +109,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("MMVAE_FORCE_DP") == "1"          # rehearsal: the data-parallel code path with ONE rank
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -123,7 +126,8 @@ def main():
 
     torch.manual_seed(0)
     model = MultiModalVAE(A, D, S, L).to(dev).set_precision(args.precision)
-    if world > 1:
+    dp = world > 1 or force_dp
+    if dp:
         parallel.broadcast_parameters(model)
         parallel.attach(model, overlap=True)
     opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
@@ -141,11 +145,19 @@ def main():
 
     # Default on one GPU: the SAME step captured once as a hipGraph (mmvae.graphs) and replayed; the three loss floats
     # are still read back on the host every step, as the reference's vae_loss does (one 16-byte read after the replay).
-    # With RCCL in the step (N > 1) launches stay eager.
+    # N > 1: two graphs, [forward, loss, backward] and [AdamW], with the RCCL all-reduce of the flat gradient arena issued
+    # eagerly between the replays (nothing of RCCL is captured).
     graphed = None
-    if world == 1 and not args.eager:
+    if not args.eager:
         from mmvae.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2)
+        reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if dp else None
+        try:
+            graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2, reduce=reduce)
+        except Exception as exc:                                 # every rank runs the same code: all of them fall back together
+            if not dp:
+                raise
+            print(f"[bench] graphed data-parallel step unavailable ({type(exc).__name__}: {exc}); eager launches instead", file=sys.stderr)
+            graphed = None
 
     def graph_step():
         graphed()
@@ -200,8 +212,10 @@ def main():
         "config": {"workload": f"MultiModalVAE full training step (fwd + vae_loss + bwd + AdamW), RNA={A} DNA={D} sites={S} latent={L}, "
                                f"batch {B} per GPU, fp32 inputs resident in HBM, random-init weights (seed 0)",
                    "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "grad_allreduce": "RCCL SUM over flat fp32 arena, decoder bucket overlapped with encoder backward" if world > 1 else None,
-                   "launch": "hipGraph replay (1 launch/step)" if graphed is not None else "eager (Python-issued launches)"},
+                   "grad_allreduce": (None if not dp else "RCCL SUM over the flat fp32 gradient arena, between the two graph replays" if graphed is not None
+                                      else "RCCL SUM over flat fp32 arena, decoder bucket overlapped with encoder backward"),
+                   "launch": ("eager (Python-issued launches)" if graphed is None else
+                              "hipGraph replay (1 launch/step)" if not dp else "2 hipGraph replays/step around the eager all-reduce")},
         "step_tflops": FLOPS_PER_SAMPLE * B / (ms * 1e-3) / 1e12,
         "step_mfma_frac": FLOPS_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.precision],
     }
@@ -252,7 +266,7 @@ def main():
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

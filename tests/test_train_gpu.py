@@ -147,6 +147,56 @@ def test_graphed_train_step_matches_eager():
     assert int(o2.state[next(iter(m2.parameters()))]["step"].item()) == n_warm + 1 + n_run
 
 
+def test_graphed_data_parallel_step_two_graphs(tmp_path):
+    """Data-parallel form of the graphed step: [forward, loss, backward] and [AdamW] captured separately, the gradient
+    all-reduce issued eagerly in between on the flat arena (one SUM all-reduce).  With a one-rank group the result
+    must equal the single-graph step; the reduce callback must see ONE contiguous fp32 tensor holding every gradient."""
+    import torch.distributed as dist
+    from mmvae.graphs import GraphedTrainStep
+    A, D, S, L, B = 782, 572, 24, 20, 512
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(B, A, generator=g).abs().to(DEV); b = torch.rand(B, D, generator=g).to(DEV)
+    site = torch.randint(0, S, (B,), generator=g).to(DEV)
+
+    def fresh():
+        torch.manual_seed(321)
+        m = MultiModalVAE(A, D, S, L).to(DEV).train()
+        engine.GLOBAL_NOISE.offset_tensor(torch.device(DEV, torch.cuda.current_device())).zero_()
+        return m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    # the group exists for BOTH runs: the Philox seed is offset by the rank once torch.distributed is initialised (engine.NoiseSource).
+    # RCCL (stream-ordered, as in production); gloo stages CUDA tensors through the host on streams of its own
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=torch.device(DEV, torch.cuda.current_device()))
+    try:
+        m1, o1 = fresh()
+        g1 = GraphedTrainStep(m1, o1, a, b, site, warmup=2)
+        ref = []
+        for _ in range(4):
+            g1(); ref.append(g1.losses()[0])
+        seen = []
+
+        def reduce(flat):
+            seen.append((flat.dtype, flat.dim(), flat.numel(), flat.is_contiguous()))
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+        m2, o2 = fresh()
+        g2 = GraphedTrainStep(m2, o2, a, b, site, warmup=2, reduce=reduce)
+        got = []
+        for _ in range(4):
+            g2(); got.append(g2.losses()[0])
+    finally:
+        dist.destroy_process_group()
+    n_params = sum(p.numel() for p in m2.parameters())
+    assert seen and all(s == (torch.float32, 1, n_params, True) for s in seen)
+    np.testing.assert_allclose(got, ref, rtol=2e-3)
+    from model_util import CHAOTIC_BIASES
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k in CHAOTIC_BIASES:
+            continue
+        d = (p1 - p2).abs()
+        assert float(d.max()) <= 10 * 1e-3 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_scaled_omics_widths(prec):
     """BASELINE configs[4] widths (RNA=20000, DNA=27000, latent=128) at a small batch: one step against the oracle

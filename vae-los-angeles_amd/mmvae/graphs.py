@@ -7,21 +7,27 @@ and replays it with a single launch per step.  What makes the step capturable:
   * no host synchronisation inside (the loss floats are read from a 16-byte device buffer AFTER the replay);
   * the Philox noise offset and the Adam step count live on the device and are advanced by kernels;
   * all buffers come from the graph's private pool; inputs are static tensors the caller copies batches into.
-Host scalars baked into the graph (lr, beta, gamma): call `recapture()` after changing them."""
+Host scalars baked into the graph (lr, beta, gamma): call `recapture()` after changing them.
+
+Data parallel (`reduce=` given): the step is captured as TWO graphs -- [forward, loss, backward] and [AdamW] -- and the
+gradient all-reduce (RCCL) is issued eagerly between the two replays on the flat gradient arena.  Nothing of RCCL is
+captured, so this needs no graph support from the collective library; the price is that the all-reduce (4.3 MB at the
+default widths) no longer overlaps the encoder backward."""
 import torch
 
 from . import functional as F_
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, a, b, site, beta=1e-3, gamma=1.0, class_weights=None, warmup=3):
+    def __init__(self, model, optimizer, a, b, site, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None):
         if not a.is_cuda:
             raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors; there is no CPU fallback")
         self.model, self.optimizer = model, optimizer
         self.a, self.b, self.site = a, b, site                  # static input buffers: copy_ new batches into them
         self.beta, self.gamma, self.class_weights = float(beta), float(gamma), class_weights
         self.warmup = warmup
-        self.graph = None
+        self.reduce = reduce                                    # callable(flat_grad_arena) or None
+        self.graph = self.graph_opt = None
         self.recapture()
 
     def _step(self):
@@ -33,24 +39,64 @@ class GraphedTrainStep:
         self.optimizer.step()
         return out4
 
+    def _fwd_bwd(self):
+        ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
+        terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
+        total, out4 = F_.fused_loss(terms, self.beta, self.gamma, self.class_weights)
+        self.optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        return out4
+
+    def _flat_grads(self):
+        """The flat fp32 gradient arena behind the parameters' .grad views (engine.VAEGraph.backward)."""
+        ps = [p for p in self.model._graph().param_list() if p.grad is not None]
+        lo = min(p.grad.data_ptr() for p in ps)
+        hi = max(p.grad.data_ptr() + p.grad.numel() * 4 for p in ps)
+        first = next(p for p in ps if p.grad.data_ptr() == lo)
+        n = (hi - lo) // 4
+        if n != sum(p.grad.numel() for p in ps):
+            raise RuntimeError("gradients are not one contiguous arena")
+        return torch.as_strided(first.grad, (n,), (1,))
+
     def recapture(self):
         self.model.train()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                            # eager warm-up: builds weight / optimiser tables, allocator pools
-            for _ in range(self.warmup):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out4 = self._step()
-        self.optimizer.note_captured_step()                      # capture recorded the launches, it did not run them
+        g = self.model._graph()
+        sync, g.grad_sync = g.grad_sync, (None if self.reduce is not None else g.grad_sync)   # two-graph form: the reduce runs between the replays
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                        # eager warm-up: builds weight / optimiser tables, allocator pools
+                for _ in range(self.warmup):
+                    if self.reduce is None:
+                        self._step()
+                    else:
+                        self._fwd_bwd()
+                        self.reduce(self._flat_grads())
+                        self.optimizer.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            if self.reduce is None:
+                with torch.cuda.graph(self.graph):
+                    self.out4 = self._step()
+            else:
+                with torch.cuda.graph(self.graph):
+                    self.out4 = self._fwd_bwd()
+                self.flat = self._flat_grads()                   # static address: the arena lives in the graph's private pool
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                    self.optimizer.step()
+            self.optimizer.note_captured_step()                  # capture recorded the launches, it did not run them
+        finally:
+            g.grad_sync = sync
         return self
 
     def __call__(self):
         """Run one training step; returns the device tensor [total, recon, class, kld] (fp32) of that step."""
         self.graph.replay()
+        if self.reduce is not None:
+            self.reduce(self.flat)
+            self.graph_opt.replay()
         self.optimizer.note_replayed_step()
         return self.out4
 
