@@ -262,7 +262,7 @@ def main():
                                          "TFLOPs": top["flops"] / top["ms_per_step"] / 1e9}
             out["gemm_ms_per_step"] = sum(k["per_step_ms"] for k in kernels)
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items() if k not in ("bytes", "flops")}
-                              for kk in kernels[:12]]
+                              for kk in kernels[:40]]
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_steps)
         print(json.dumps(out))

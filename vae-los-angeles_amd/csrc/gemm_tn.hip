@@ -294,30 +294,37 @@ extern "C" int mmvae_debug_stamps_tn(unsigned long long* out12, int reset) {
 }
 #endif
 
-// dW[n][k] += sum_z slab[z][n][k]   (fixed summation order -> bitwise reproducible weight gradients)
+// dW[n][k] += sum_z slab[z][n][k].  Splits are summed in groups of TN_RG (blockIdx.y): ONE group (<= TN_RG splits, the large
+// weight matrices) is a fixed-order sum -> bitwise reproducible gradients; more groups (small matrices split hundreds of
+// ways) add their partial sums with f32 atomics, nsplit / TN_RG ways per address instead of nsplit ways from the GEMM itself.
+constexpr int TN_RG = 32;
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, int nsplit, long nk, float* __restrict__ dW,
                                                         long ldw, int K) {
+    const int z0 = blockIdx.y * TN_RG, z1 = min(nsplit, z0 + TN_RG);
+    const bool single = gridDim.y == 1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
 #pragma unroll 8
-        for (int z = 0; z < nsplit; ++z) s += slab[z * nk + i];       // independent loads: 8 in flight per thread
+        for (int z = z0; z < z1; ++z) s += slab[z * nk + i];          // independent loads: 8 in flight per thread
         const long n = i / K, k = i - n * K;
-        dW[n * ldw + k] += s;
+        if (single) dW[n * ldw + k] += s;
+        else unsafeAtomicAdd(dW + n * ldw + k, s);
     }
 }
 
-// Slabs pay when a LARGE weight matrix is split a few dozen ways (tens of MB of atomics otherwise); a small matrix split
-// hundreds of ways (heads, 40 x 256) would turn the reduce into a latency-bound crawl: those keep the f32 atomics.
+// Slabs (plain stores of every split's partial tile + this reduce) instead of f32 atomics from the GEMM epilogue whenever the
+// workspace holds them: atomics from hundreds of splits onto the same few thousand addresses were what the small dW GEMMs
+// (latent / class widths) spent their time on.
 static bool tn_use_slab(const mmvae_gemm_tn_args* a, int nsplit) {
     const long nk = (long)a->N * a->K;
-    return a->slab && nsplit > 1 && nsplit <= 64 && nk >= 32768 && nsplit * nk <= a->slab_elems;
+    return a->slab && nsplit > 1 && nsplit * nk <= a->slab_elems;
 }
 
 static int tn_reduce(const mmvae_gemm_tn_args* a, int nsplit, hipStream_t st) {
     const long nk = (long)a->N * a->K;
     int grid = (int)((nk + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid), dim3(256), 0, st, a->slab, nsplit, nk, a->dw, a->lddw, a->K);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid, (nsplit + TN_RG - 1) / TN_RG), dim3(256), 0, st, a->slab, nsplit, nk, a->dw, a->lddw, a->K);
     MM_CHECK_LAUNCH();
     return 0;
 }

@@ -363,7 +363,14 @@ class VAEGraph:
         self._prep_key = None
         self.noise = GLOBAL_NOISE
         self.grad_sync = None          # mmvae.parallel.GradAllReduce (early/final hooks) under data parallelism
-        self.overlap_dw = os.environ.get("MMVAE_OVERLAP_DW", "1") != "0"
+        # Independent chains on side HIP streams (EncoderA beside EncoderB, the small decoders beside DecoderB, the dW GEMMs beside
+        # the dX chain, the noise launch beside the first GEMMs).  OFF by default since the kernels got faster: overlapped
+        # HBM-bound kernels only take turns, and the fork/join edges cost more than they buy (2.19 -> 2.15 ms/step at B = 65 536).
+        self.overlap_dw = os.environ.get("MMVAE_OVERLAP_DW", "0") != "0"
+        self.overlap_enc = os.environ.get("MMVAE_OVERLAP_ENC", "1") != "0" and self.overlap_dw
+        self.overlap_dec = os.environ.get("MMVAE_OVERLAP_DEC", "1") != "0" and self.overlap_dw
+        self.overlap_bwd = os.environ.get("MMVAE_OVERLAP_BWD", "1") != "0" and self.overlap_dw
+        self.overlap_small = os.environ.get("MMVAE_OVERLAP_SMALL_DW", "0") != "0"     # only the tiny-output dW GEMMs aside: measured slower too
 
     def param_list(self):
         out = []
@@ -406,7 +413,7 @@ class VAEGraph:
         # beside the first-layer GEMMs (nothing reads a mask before the second GEMM, eps before the fusion), EncoderA beside
         # EncoderB, the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
         main = torch.cuda.current_stream()
-        side = _side_stream(dev) if (self.overlap_dw and xa is not None and xb is not None) else None
+        side = _side_stream(dev) if (self.overlap_enc and xa is not None and xb is not None) else None
         nside = _side_stream(dev, 1) if (side is not None and self.noise._injected is None) else None
         noise_ev = None
         if nside is not None:
@@ -454,7 +461,7 @@ class VAEGraph:
         saved.update(eps=eps, logvar=logvar.detach(), n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
         outs, saved["dec"] = [None] * len(self.decoders), [None] * len(self.decoders)
         order = sorted(range(len(self.decoders)), key=lambda i: -sum(l.weight.numel() for l in self.decoders[i].linears))
-        dside = _side_stream(dev) if (self.overlap_dw and len(order) > 1) else None
+        dside = _side_stream(dev) if (self.overlap_dec and len(order) > 1) else None
         if dside is not None:
             _fork(main, dside)
         for rank_, i in enumerate(order):               # largest decoder on the main stream, the others beside it
@@ -506,9 +513,16 @@ class VAEGraph:
         def tn(prec_, p, q, *a, **kw):
             ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         main = torch.cuda.current_stream()
-        side = _side_stream(dev) if self.overlap_dw else None
+        # "small" (default): only the dW GEMMs with a tiny output (latent / class widths: a few batch steps per workgroup, then
+        # atomics -- latency-bound at 20-30 us each for a few MB) run on the side stream, under the big launches of the dX
+        # chain; the large dW GEMMs are HBM-bound like the chain itself and only take turns with it.
+        small_only = self.overlap_small and not self.overlap_bwd
+        side = _side_stream(dev) if (self.overlap_bwd or self.overlap_small) else None
         if side is not None:
-            def tn(prec_, p, q, *a, **kw):
+            def tn(prec_, p, q, dw, db, N, K, **kw):
+                if small_only and N * K > 16384:
+                    return ops.gemm_tn(prec_, p, q, dw, db, N, K, slab=slab, **kw)
+                a = (dw, db, N, K)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
