@@ -23,10 +23,13 @@ if tag == "DecoderB.L2.dW":            # dW[572,512] += g_b^T H2
     P, Q = bf(M, 572), bf(M, 512)
     dw, db = torch.zeros(572, 512, device=dev), torch.zeros(572, device=dev)
     run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 572, 512)
-elif tag == "EncoderB.L0.dW":          # dW[512,572] += dy^T b   (b fp32)
-    P = bf(M, 512); Q = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
+elif tag == "EncoderB.L0.dW":          # dW[512,572] += dy^T b with dy = BatchNorm-backward correction of d applied on the load (b fp32)
+    P = bf(M, 512); Y = bf(M, 512); Q = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
+    f = lambda: torch.rand(512, device=dev) + 0.5
+    mean, rstd, coef = f() - 1.0, f(), torch.stack([f(), (f() - 1.0) * 0.1, (f() - 1.0) * 0.1]).contiguous()
     dw, db = torch.zeros(512, 572, device=dev), torch.zeros(512, device=dev)
-    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 512, 572)
+    slab = torch.empty(1 << 24, device=dev)
+    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 512, 572, p_prologue=(Y[i % nbuf], mean, rstd, coef), slab=slab)
 elif tag == "EncoderB.L0.fwd":         # y[B,512] = b W^T (+ BN statistics)
     A = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
     W = torch.randn(512, 572, device=dev) / 24; bias = torch.zeros(512, device=dev)
