@@ -356,13 +356,22 @@ __global__ __launch_bounds__(256) void scale_if_needed_kernel(T* x, long n, cons
 // ------------------------------------------------------------------------------------------
 // `offset_dev` (optional) is a device-resident running offset added to `offset`: it lets a captured hipGraph draw
 // fresh noise on every replay (mmvae_counter_add advances it at the end of the step).
+// 16 keep decisions (bytes) per quad from TWO Philox calls: each 32-bit word decides two bytes by its 16-bit halves against
+// thresh >> 16 (keep probability quantised to 1/65536: 0.9 -> 0.899994).  One word per byte made this launch VALU-bound
+// (~150 integer lane-ops per call, 15 M calls for the 59 MB of masks of one step: 42 us); counters q*4+2, q*4+3 stay unused.
 __device__ __forceinline__ void mask_quad(uint8_t* mask, long n, long q, uint32_t thresh, uint64_t seed, uint64_t offset) {
         uint32_t w[4];
+        const uint32_t t16 = thresh == 0xFFFFFFFFu ? 0x10000u : thresh >> 16;      // keep probability 1: every 16-bit value passes
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             uint32_t r[4];
             Philox::gen(seed, offset + (uint64_t)q * 4 + k, 0x4D41534Bull /* "MASK" */, r);
-            w[k] = (r[0] < thresh ? 1u : 0u) | (r[1] < thresh ? 0x100u : 0u) | (r[2] < thresh ? 0x10000u : 0u) | (r[3] < thresh ? 0x1000000u : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t a = r[2 * h], b = r[2 * h + 1];
+                w[2 * k + h] = ((a & 0xffffu) < t16 ? 1u : 0u) | ((a >> 16) < t16 ? 0x100u : 0u) |
+                               ((b & 0xffffu) < t16 ? 0x10000u : 0u) | ((b >> 16) < t16 ? 0x1000000u : 0u);
+            }
         }
         if (q * 16 + 16 <= n) { uint4 v = {w[0], w[1], w[2], w[3]}; *(uint4*)(mask + q * 16) = v; }
         else for (long i = q * 16; i < n; ++i) mask[i] = (uint8_t)((w[(i - q * 16) >> 2] >> (8 * ((i - q * 16) & 3))) & 0xff);
