@@ -152,21 +152,40 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
     if (use_lds) { for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) sT[i] = 0.f; __syncthreads(); }
     const int b0 = blockIdx.x * rows_per_block, b1 = min(a.B, b0 + rows_per_block);
     const float inv_n = 1.f / (float)a.n_mod;
-    for (long i = (long)b0 * a.L + threadIdx.x; i < (long)b1 * a.L; i += blockDim.x) {
-        const int b = (int)(i / a.L), l = (int)(i % a.L);
-        float dz = a.dz[(long)b * a.lddz + l];
-        if (a.dz2) dz += a.dz2[(long)b * a.lddz + l];
-        if (a.dz3) dz += a.dz3[(long)b * a.lddz + l];
-        const float gm = a.g_mu ? a.g_mu[i] : 0.f, gl = a.g_lv ? a.g_lv[i] : 0.f;
-        float dmu = gm + dz;
-        float dlv = gl + dz * a.eps[i] * expf(0.5f * a.logvar[i]) * 0.5f;
-        if (a.n_mod > 1) { dmu *= inv_n; dlv *= inv_n; }
-        a.d_heads[(long)b * a.ld_heads + l] = dmu;
-        a.d_heads[(long)b * a.ld_heads + a.L + l] = dlv;
-        if (a.d_table) {
-            const long s = a.site[b];
-            if (use_lds) { atomicAdd(&sT[s * L2 + l], dmu); atomicAdd(&sT[s * L2 + a.L + l], dlv); }
-            else { unsafeAtomicAdd(&a.d_table[s * L2 + l], dmu); unsafeAtomicAdd(&a.d_table[s * L2 + a.L + l], dlv); }
+    // U elements per thread are loaded before any is processed (stores may alias loads for the compiler): with one element
+    // per iteration a thread had ~7 dependent-latency loads in flight at a time and the launch was latency-bound (43 us for 40 MB)
+    constexpr int U = 4;
+    const long iend = (long)b1 * a.L;
+    for (long i0 = (long)b0 * a.L + threadIdx.x; i0 < iend; i0 += (long)U * blockDim.x) {
+        float dz[U], gm[U], gl[U], ep[U], lv[U];
+        int bb[U], ll[U];
+        long sidx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = min(i0 + (long)u * blockDim.x, iend - 1);        // clamped: the loads always issue
+            const int b = (int)(i / a.L), l = (int)(i - (long)b * a.L);
+            bb[u] = b; ll[u] = l;
+            dz[u] = a.dz[(long)b * a.lddz + l];
+            if (a.dz2) dz[u] += a.dz2[(long)b * a.lddz + l];
+            if (a.dz3) dz[u] += a.dz3[(long)b * a.lddz + l];
+            gm[u] = a.g_mu ? a.g_mu[i] : 0.f; gl[u] = a.g_lv ? a.g_lv[i] : 0.f;
+            ep[u] = a.eps[i]; lv[u] = a.logvar[i];
+            sidx[u] = a.d_table ? a.site[b] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + (long)u * blockDim.x >= iend) break;
+            const int b = bb[u], l = ll[u];
+            float dmu = gm[u] + dz[u];
+            float dlv = gl[u] + dz[u] * ep[u] * expf(0.5f * lv[u]) * 0.5f;
+            if (a.n_mod > 1) { dmu *= inv_n; dlv *= inv_n; }
+            a.d_heads[(long)b * a.ld_heads + l] = dmu;
+            a.d_heads[(long)b * a.ld_heads + a.L + l] = dlv;
+            if (a.d_table) {
+                const long sx = sidx[u];
+                if (use_lds) { atomicAdd(&sT[sx * L2 + l], dmu); atomicAdd(&sT[sx * L2 + a.L + l], dlv); }
+                else { unsafeAtomicAdd(&a.d_table[sx * L2 + l], dmu); unsafeAtomicAdd(&a.d_table[sx * L2 + a.L + l], dlv); }
+            }
         }
     }
     if (use_lds && a.d_table) {
@@ -525,7 +544,7 @@ extern "C" int mmvae_fuse_reparam_fwd(const mmvae_fuse_fwd_args* a, void* stream
 extern "C" int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* a, void* stream) {
     if (!a || a->B <= 0 || a->L <= 0 || a->n_mod <= 0 || !a->dz || !a->eps || !a->logvar || !a->d_heads) return MMVAE_ERR_ARG;
     if (a->d_table && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
-    const int rows_per_block = 256;
+    const int rows_per_block = 128;          // 512 workgroups at B = 65 536: two per CU
     const int grid = (a->B + rows_per_block - 1) / rows_per_block;
     const size_t lds = a->d_table ? (size_t)a->S * 2 * a->L * sizeof(float) : 0;
     const int use_lds = lds > 0 && lds <= 48 * 1024;
