@@ -235,11 +235,11 @@ def main():
             t_mfma = dom["flops"] / (MFMA_PEAK_TFLOPS[args.precision] * 1e12)
             if t_hbm >= t_mfma:
                 out["roofline"] = {"bound": "hbm", "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["tag"], B), "kernel": dom["tag"],
+                                   "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["tag"], B) if args.precision == "bf16" else None, "kernel": dom["tag"],
                                    "launch_ms": dom["ms"], "algorithmic_bytes": dom["bytes"]}
             else:
                 out["roofline"] = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": MFMA_PEAK_TFLOPS[args.precision],
-                                   "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": pmc_traffic(dom["tag"], B),
+                                   "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": pmc_traffic(dom["tag"], B) if args.precision == "bf16" else None,
                                    "kernel": dom["tag"], "launch_ms": dom["ms"], "algorithmic_flops": dom["flops"]}
             out["roofline"]["definition"] = ("largest single GEMM launch of the step; duration = HIP events on the launch stream around that "
                                              "launch over the timed steps (eager pass), bytes = algorithmic operand + result bytes of the launch")
