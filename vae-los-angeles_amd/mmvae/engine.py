@@ -370,7 +370,6 @@ class VAEGraph:
         self.overlap_enc = os.environ.get("MMVAE_OVERLAP_ENC", "1") != "0" and self.overlap_dw
         self.overlap_dec = os.environ.get("MMVAE_OVERLAP_DEC", "1") != "0" and self.overlap_dw
         self.overlap_bwd = os.environ.get("MMVAE_OVERLAP_BWD", "1") != "0" and self.overlap_dw
-        self.overlap_small = os.environ.get("MMVAE_OVERLAP_SMALL_DW", "0") != "0"     # only the tiny-output dW GEMMs aside: measured slower too
 
     def param_list(self):
         out = []
@@ -513,16 +512,10 @@ class VAEGraph:
         def tn(prec_, p, q, *a, **kw):
             ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         main = torch.cuda.current_stream()
-        # "small" (default): only the dW GEMMs with a tiny output (latent / class widths: a few batch steps per workgroup, then
-        # atomics -- latency-bound at 20-30 us each for a few MB) run on the side stream, under the big launches of the dX
-        # chain; the large dW GEMMs are HBM-bound like the chain itself and only take turns with it.
-        small_only = self.overlap_small and not self.overlap_bwd
-        side = _side_stream(dev) if (self.overlap_bwd or self.overlap_small) else None
+        # all dW GEMMs of one backward share the slab workspace: they must stay on ONE stream (main, or the side stream)
+        side = _side_stream(dev) if self.overlap_bwd else None
         if side is not None:
-            def tn(prec_, p, q, dw, db, N, K, **kw):
-                if small_only and N * K > 16384:
-                    return ops.gemm_tn(prec_, p, q, dw, db, N, K, slab=slab, **kw)
-                a = (dw, db, N, K)
+            def tn(prec_, p, q, *a, **kw):
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
