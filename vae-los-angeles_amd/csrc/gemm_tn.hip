@@ -155,7 +155,7 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) Mma<CT>::mma(acc[a][b], af[a], bf[b]);
+            for (int b = 0; b < 4; ++b) Mma<CT>::mma(acc[a][b], bf[b], af[a]);     // swapped: a lane holds 4 consecutive k of one n (epilogue)
         if (do_bias) {                      // column sums of P straight from the A fragments (VALU is idle here)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -246,23 +246,33 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
         if (nt > 3) kstep(rp1, rq1, 3, 1, false, false, 0);
     }
 
+    // The MFMA operands are swapped (Q fragment as "A", P fragment as "B"), so accumulator (a, b) holds, in lane (li = lane & 15,
+    // lg = lane >> 4), dW[n = 16a + li][k = 16b + 4lg + j], j = 0..3: FOUR CONSECUTIVE k.  A split's partial tile goes to the slab
+    // as 16-byte stores (16 instead of 64 store instructions per lane: the scalar form cost 10-29 k cycles per workgroup, more
+    // than the 4 batch steps of a tiny-output GEMM).
+    const bool vec4 = slab != nullptr && (K & 3) == 0 && ((uintptr_t)slab & 15) == 0;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+        const int n = n0 + wr * 64 + a * 16 + (lane & 15);
+        if (n >= N) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wr * 64 + a * 16 + (lane >> 4) * 4 + j;
-            if (n >= N) continue;
+        for (int b = 0; b < 4; ++b) {
+            const int k = k0 + wc * 64 + b * 16 + (lane >> 4) * 4;
+            if (k >= K) continue;
+            if (slab) {
+                // slab form: this split's partial tile is stored plainly into slab[zz] and summed by tn_reduce_kernel
+                float* sp = slab + ((long)zz * N + n) * K + k;
+                if (vec4 && k + 4 <= K) *(f32x4*)sp = acc[a][b];
+                else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int k = k0 + wc * 64 + b * 16 + (lane & 15);
-                if (k < K) {
-                    // slab form: this split's partial tile is stored plainly into slab[zz] and summed by tn_reduce_kernel
-                    // (deterministic, no memory-side atomics); otherwise f32 atomics straight into dW
-                    if (slab) slab[((long)zz * N + n) * K + k] = acc[a][b][j];
-                    else unsafeAtomicAdd(dW + (long)n * ldw + k, acc[a][b][j]);
+                    for (int j = 0; j < 4; ++j) if (k + j < K) sp[j] = acc[a][b][j];
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k + j < K) unsafeAtomicAdd(dW + (long)n * ldw + k + j, acc[a][b][j]);       // f32 atomics straight into dW
             }
         }
+    }
     if (do_bias) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
