@@ -21,12 +21,13 @@ lib.mmvae_debug_stamps_tn.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 P = [torch.randn(M, ops.ceil_to(N, 8), device=dev).bfloat16() for _ in range(3)]
 Q = [torch.randn(M, ops.ceil_to(K, 8), device=dev).bfloat16() for _ in range(3)]
 dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+slab = torch.empty(1 << 25, device=dev)            # as in the engine: partial tiles of the batch splits go to a slab workspace
 buf = (C.c_uint64 * 12)()
 
 
 def run(reps):
     for i in range(reps):
-        ops.gemm_tn(PREC_BF16, P[i % 3], Q[i % 3], dw, db, N, K)
+        ops.gemm_tn(PREC_BF16, P[i % 3], Q[i % 3], dw, db, N, K, slab=slab)
     torch.cuda.synchronize()
 
 

@@ -107,6 +107,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
             rb[i].v = *(const decltype(rb[i].v)*)(W + ((unsigned)(col0 + wr_) * (unsigned)ldw + (unsigned)(kt * BK + ch * EPC)));
         }
     };
+    const bool a_tail = Src::PAD_TAIL && (K & 7) != 0;        // kernel-uniform
     auto stage = [&](typename Src::Raw (&ra)[A_PER], Chunk<CT> (&rb)[4], int kt, int buf) {      // registers -> LDS buffer
         unsigned char* sA = smem + buf * NtLds<WN>::BUF;
         unsigned char* sB = sA + TILE * ROW_BYTES;
@@ -114,7 +115,10 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
         for (int i = 0; i < A_PER; ++i) {
             int c = tid + NTH * i, r = c >> 3, ch = c & 7;
             Chunk<CT> o;
-            src.finish(ra[i], row0 + r, kt * BK + ch * EPC, o, aux);
+            // unmasked unless the rows of a 2-byte A end inside a 16-byte chunk (K % 8 != 0): the pad elements of a caller's
+            // buffer may hold anything, and NaN x (zero weight padding) would reach valid outputs.  See gemm_src.h.
+            if (a_tail) src.finish(ra[i], row0 + r, kt * BK + ch * EPC, o, aux);
+            else src.finish_fast(ra[i], kt * BK + ch * EPC, o, aux);
             *(decltype(o.v)*)(sA + swz(r, ch)) = o.v;
         }
 #pragma unroll

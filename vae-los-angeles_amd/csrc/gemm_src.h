@@ -34,6 +34,7 @@ template <typename CT, typename AT, int VEC>
 struct SrcPlain {
     static constexpr int EPC = Mma<CT>::EPC;
     static constexpr bool NEEDS_AUX = false;
+    static constexpr bool PAD_TAIL = sizeof(AT) == 2;      // 2-byte rows are read in whole 16-byte chunks: a row may end inside one
     const AT* p; long lda; int M, K;
     typedef RawVec<AT, EPC> Raw;
     __device__ __forceinline__ void init(float*, int, int) const {}
@@ -45,6 +46,28 @@ struct SrcPlain {
             r.v = *(const bf16x8*)(p + (ro + (unsigned)min(k, ((K + 7) & ~7) - 8)));      // internal buffers: rows padded to 8 elements
         } else {
             load_chunk_f32<EPC, VEC>(r, p, ro, k, K);
+        }
+    }
+    // finish_fast: NO masking.  What lies beyond the operand (rows clamped to M-1, columns clamped into the row, zero pads of
+    // the activation buffers) is finite, and it only ever meets zero weight padding (NT), a zeroed P row (TN) or an output
+    // element that is never stored -- the masking selects and the tail branch were ~100 cycles per chunk of the registers ->
+    // LDS stage, 8 chunks per K step.  finish_rows: rows >= M become zeros (the P operand of the dW GEMM: batch rows past the
+    // split must not enter the reduction).  finish: rows and columns masked (kept for callers that need exact zeros).
+    __device__ __forceinline__ void finish_fast(const Raw& r, int, Chunk<CT>& o, const float*) const {
+        if constexpr (sizeof(AT) == 2) o.v = r.v;
+        else {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) o.set(i, r.v[i]);
+        }
+    }
+    __device__ __forceinline__ void finish_rows(const Raw& r, int row, int, Chunk<CT>& o, const float*) const {
+        const bool ok = row < M;
+        if constexpr (sizeof(AT) == 2) {
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            o.v = ok ? r.v : z;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) o.set(i, ok ? r.v[i] : 0.f);
         }
     }
     __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float*) const {
@@ -70,6 +93,7 @@ template <typename CT>
 struct SrcBnReluDrop {
     static constexpr int EPC = Mma<CT>::EPC;
     static constexpr bool NEEDS_AUX = true;
+    static constexpr bool PAD_TAIL = false;                // K = a hidden width (multiple of 64)
     const CT* y; long ldy; int M, K;
     const float* scale; const float* shift;
     const uint8_t* mask; long ldm; float inv_keep;
@@ -94,6 +118,16 @@ struct SrcBnReluDrop {
             for (int i = 0; i < EPC / 4; ++i) r.m[i] = 0x01010101u;
         }
     }
+    __device__ __forceinline__ void finish_fast(const Raw& r, int k, Chunk<CT>& o, const float* aux) const {      // k < K (hidden widths)
+        const int kk = min(k, 512 - EPC);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) {
+            const float v = fmaxf(r.y.get(i) * aux[kk + i] + aux[512 + kk + i], 0.f);
+            const float keep = ((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu) ? inv_keep : 0.f;
+            o.set(i, v * keep);
+        }
+    }
+    __device__ __forceinline__ void finish_rows(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const { finish(r, row, k, o, aux); }
     __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const {
         bool ok = row < M && k < K;
 #pragma unroll
@@ -114,6 +148,7 @@ template <typename CT>
 struct SrcBnBwdApply {
     static constexpr int EPC = Mma<CT>::EPC;
     static constexpr bool NEEDS_AUX = true;
+    static constexpr bool PAD_TAIL = false;
     const CT* d; long ldd; const CT* y; long ldy; int M, K;          // K = number of columns (the layer width)
     const float* mean; const float* rstd; const float* coef;          // coef: [3][K]
     struct Raw { RawVec<CT, EPC> d, y; };
@@ -136,6 +171,8 @@ struct SrcBnBwdApply {
             for (int i = 0; i < 4; ++i) { r.d.v[i] = a[i]; r.y.v[i] = b[i]; }
         }
     }
+    __device__ __forceinline__ void finish_fast(const Raw& r, int k, Chunk<CT>& o, const float* aux) const { finish(r, 0, k, o, aux); }
+    __device__ __forceinline__ void finish_rows(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const { finish(r, row, k, o, aux); }
     __device__ __forceinline__ void finish(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const {
         const bool ok = row < M && k < K;
         const int c = k & (TILE - 1);

@@ -135,9 +135,9 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
             int m = m_begin + t * G::MT + r;
             m = m >= m_end ? M : m;
             Chunk<CT> o;
-            ps.finish(rp[i], m, n0 + ch * EPC, o, auxp);
+            ps.finish_rows(rp[i], m, n0 + ch * EPC, o, auxp);        // P rows past the split are zeros: they drop out of the reduction
             *(decltype(o.v)*)(sP + G::chunk_off(r, ch)) = o.v;
-            qs.finish(rq[i], m, k0 + ch * EPC, o, aux);
+            qs.finish_fast(rq[i], k0 + ch * EPC, o, aux);             // Q unmasked (finite, and multiplied by the zeroed P rows)
             *(decltype(o.v)*)(sQ + G::chunk_off(r, ch)) = o.v;
         }
     };
