@@ -208,14 +208,27 @@ __device__ __forceinline__ void store_vec(GT* p, const float* v) {
     else for (int e = 0; e < V; ++e) p[e] = o[e];
 }
 
-// Flat index i = r * vpr + cv walks the [B][A/V] vector grid with a grid stride; (r, cv) are advanced incrementally -- an
-// integer division per vector made these parts VALU-bound (~40 lane-ops per 8 bytes), not HBM-bound.
+// Flat index i = r * vpr + cv walks the [B][W/V] vector grid with a grid stride.  The element offsets of the three matrices
+// (prediction, target, gradient; row pitches ld[k]) are advanced incrementally: an integer division per vector made these parts
+// VALU-bound (~40 lane-ops per 8 bytes), and even r * ld[k] per vector is six quarter-rate 64-bit multiply-adds that sit
+// between a wave's loop iterations, i.e. in series with its memory latency.  step / fix are wave-uniform.
 struct RowWalk {
-    unsigned r, cv, dr, dc, vpr;
-    __device__ __forceinline__ RowWalk(unsigned i0, unsigned stride, unsigned vpr_) : vpr(vpr_) {
-        r = i0 / vpr; cv = i0 - r * vpr; dr = stride / vpr; dc = stride - dr * vpr;
+    unsigned cv, dc, vpr;
+    long o[3], step[3], fix[3];
+    __device__ __forceinline__ RowWalk(unsigned i0, unsigned stride, unsigned vpr_, int V, long ld0, long ld1, long ld2) : vpr(vpr_) {
+        const unsigned r = i0 / vpr, dr = stride / vpr;
+        cv = i0 - r * vpr; dc = stride - dr * vpr;
+        const long ld[3] = {ld0, ld1, ld2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[k] = r * ld[k] + (long)cv * V; step[k] = dr * ld[k] + (long)dc * V; fix[k] = ld[k] - (long)vpr * V; }
     }
-    __device__ __forceinline__ void next() { r += dr; cv += dc; if (cv >= vpr) { cv -= vpr; ++r; } }
+    __device__ __forceinline__ void next() {
+        cv += dc;
+        const bool wrap = cv >= vpr;
+        if (wrap) cv -= vpr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] += step[k] + (wrap ? fix[k] : 0L);
+    }
 };
 
 // U vectors per thread are loaded BEFORE any is processed: the stores of one iteration may alias the loads of the next as far
@@ -223,82 +236,78 @@ struct RowWalk {
 // of loaded latency is the 3.7 TB/s this kernel was stuck at.
 constexpr int LOSS_U = 4;
 
-template <typename GT, int V>
-__device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, long stride) {
+// One streaming pass over a prediction / target pair of [B][W] fp32 matrices in V-wide vectors; `f(p, t, g)` returns the loss
+// term of one element and its gradient.  The hot loop has no per-vector conditions: iterations in which all U vectors of the
+// thread exist run unchecked, the (< U) vectors left are taken one at a time, and the pad columns of the gradient rows (the GEMM
+// operand contract: zeros up to the next multiple of 8) are written by a separate row loop.
+template <typename GT, int V, bool HAS_G, typename F>
+__device__ __forceinline__ float stream_part(const float* __restrict__ pred, long ld_p, const float* __restrict__ tgt, long ld_t,
+                                             GT* g_out, long ld_g, int B, int W, long tid0, long stride, F f) {
     float acc = 0.f;
-    const int vpr = a.A / V;
-    const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
-    RowWalk w((unsigned)tid0, (unsigned)stride, (unsigned)vpr);
-    for (unsigned i = (unsigned)tid0; i < total; i += LOSS_U * (unsigned)stride) {
+    const unsigned vpr = (unsigned)(W / V);
+    const long total = (long)B * vpr;                            // < 2^32 checked on the host
+    RowWalk w((unsigned)tid0, (unsigned)stride, vpr, V, ld_p, ld_t, ld_g);
+    auto one = [&](const float (&x)[V], const float (&t)[V], long og) {
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc += f(x[e], t[e], g[e]);
+        if constexpr (HAS_G) store_vec<GT, V>(g_out + og, g);
+    };
+    long i = tid0;
+    for (; i + (LOSS_U - 1) * stride < total; i += LOSS_U * stride) {
         float x[LOSS_U][V], t[LOSS_U][V];
-        unsigned rr[LOSS_U], cc[LOSS_U];
-        bool ok[LOSS_U];
+        long og[LOSS_U];
 #pragma unroll
         for (int u = 0; u < LOSS_U; ++u) {
-            ok[u] = i + u * (unsigned)stride < total && i + u * (unsigned)stride >= i;
-            rr[u] = ok[u] ? w.r : 0u; cc[u] = ok[u] ? w.cv * V : 0u;          // clamped: the loads always issue
-            VLoad<float, V>::ld(a.recon_a + (long)rr[u] * a.ld_ra + cc[u], x[u]);
-            VLoad<float, V>::ld(a.a + (long)rr[u] * a.ld_a + cc[u], t[u]);
+            VLoad<float, V>::ld(pred + w.o[0], x[u]);
+            VLoad<float, V>::ld(tgt + w.o[1], t[u]);
+            og[u] = w.o[2];
             w.next();
         }
 #pragma unroll
-        for (int u = 0; u < LOSS_U; ++u) {
-            if (!ok[u]) continue;
-            float g[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) { const float d = x[u][e] - t[u][e]; acc += d * d; g[e] = 2.f * d; }
-            if (a.g_a) {
-                GT* gp = (GT*)a.g_a + (long)rr[u] * a.ld_ga;
-                store_vec<GT, V>(gp + cc[u], g);
-                if ((int)cc[u] + V >= a.A)                   // last vector of the row: zero the pad columns (GEMM operand contract)
-                    for (int e = a.A; e < (int)a.ld_ga && e < ((a.A + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
-            }
-        }
+        for (int u = 0; u < LOSS_U; ++u) one(x[u], t[u], og[u]);
+    }
+    for (; i < total; i += stride) {
+        float x[V], t[V];
+        VLoad<float, V>::ld(pred + w.o[0], x);
+        VLoad<float, V>::ld(tgt + w.o[1], t);
+        const long og = w.o[2];
+        w.next();
+        one(x, t, og);
+    }
+    if constexpr (HAS_G) {
+        const int pad_end = min((int)ld_g, (W + 7) & ~7);
+        if (pad_end > W)
+            for (long r = tid0; r < B; r += stride)
+                for (int e = W; e < pad_end; ++e) g_out[r * ld_g + e] = from_f32<GT>(0.f);
     }
     return acc;
 }
 
 template <typename GT, int V>
+__device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, long stride) {
+    auto f = [](float x, float t, float& g) { const float d = x - t; g = 2.f * d; return d * d; };
+    if (a.g_a) return stream_part<GT, V, true>(a.recon_a, a.ld_ra, a.a, a.ld_a, (GT*)a.g_a, a.ld_ga, a.B, a.A, tid0, stride, f);
+    return stream_part<GT, V, false>(a.recon_a, a.ld_ra, a.a, a.ld_a, (GT*)nullptr, 0, a.B, a.A, tid0, stride, f);
+}
+
+template <typename GT, int V, bool WRT_LOGIT>
+__device__ __forceinline__ float bce_part_g(const mmvae_loss_args& a, long tid0, long stride) {
+    auto f = [](float pe, float te, float& g) {
+        const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
+        const float pq = (1.f - pe) * pe, d = pe - te;
+        // torch: grad_p = (p - t) / max(p (1 - p), 1e-12); w.r.t. the logit that times p (1 - p): exactly (p - t) unless clamped
+        if constexpr (WRT_LOGIT) g = pq >= 1e-12f ? d : d * pq * 1e12f;
+        else g = d * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f));
+        return -(te * lp + (1.f - te) * l1p);
+    };
+    if (a.g_b) return stream_part<GT, V, true>(a.recon_b, a.ld_rb, a.b, a.ld_b, (GT*)a.g_b, a.ld_gb, a.B, a.D, tid0, stride, f);
+    return stream_part<GT, V, false>(a.recon_b, a.ld_rb, a.b, a.ld_b, (GT*)nullptr, 0, a.B, a.D, tid0, stride, f);
+}
+
+template <typename GT, int V>
 __device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, long stride) {
-    float acc = 0.f;
-    const int vpr = a.D / V;
-    const unsigned total = (unsigned)a.B * (unsigned)vpr;        // < 2^32 checked on the host: 32-bit index math
-    RowWalk w((unsigned)tid0, (unsigned)stride, (unsigned)vpr);
-    for (unsigned i = (unsigned)tid0; i < total; i += LOSS_U * (unsigned)stride) {
-        float p[LOSS_U][V], t[LOSS_U][V];
-        unsigned rr[LOSS_U], cc[LOSS_U];
-        bool ok[LOSS_U];
-#pragma unroll
-        for (int u = 0; u < LOSS_U; ++u) {
-            ok[u] = i + u * (unsigned)stride < total && i + u * (unsigned)stride >= i;
-            rr[u] = ok[u] ? w.r : 0u; cc[u] = ok[u] ? w.cv * V : 0u;
-            VLoad<float, V>::ld(a.recon_b + (long)rr[u] * a.ld_rb + cc[u], p[u]);
-            VLoad<float, V>::ld(a.b + (long)rr[u] * a.ld_b + cc[u], t[u]);
-            w.next();
-        }
-#pragma unroll
-        for (int u = 0; u < LOSS_U; ++u) {
-            if (!ok[u]) continue;
-            float g[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const float pe = p[u][e], te = t[u][e];
-                const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
-                acc -= te * lp + (1.f - te) * l1p;
-                const float pq = (1.f - pe) * pe, d = pe - te;
-                // torch: grad_p = (p - t) / max(p (1 - p), 1e-12); w.r.t. the logit that times p (1 - p): exactly (p - t) unless clamped
-                if (a.grad_b_wrt_logit) g[e] = pq >= 1e-12f ? d : d * pq * 1e12f;
-                else g[e] = d * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f));
-            }
-            if (a.g_b) {
-                GT* gp = (GT*)a.g_b + (long)rr[u] * a.ld_gb;
-                store_vec<GT, V>(gp + cc[u], g);
-                if ((int)cc[u] + V >= a.D)
-                    for (int e = a.D; e < (int)a.ld_gb && e < ((a.D + 7) & ~7); ++e) gp[e] = from_f32<GT>(0.f);
-            }
-        }
-    }
-    return acc;
+    return a.grad_b_wrt_logit ? bce_part_g<GT, V, true>(a, tid0, stride) : bce_part_g<GT, V, false>(a, tid0, stride);
 }
 
 template <typename GT, int VA, int VD>
@@ -562,7 +571,8 @@ static int launch_loss(const mmvae_loss_args* a, hipStream_t st) {
         if (vd == 1 && a->recon_b && a->D % v == 0 && al(a->recon_b, a->ld_rb, v, 4) && al(a->b, a->ld_b, v, 4) && al(a->g_b, a->ld_gb, v, sizeof(GT))) vd = v;
     }
     const long work = (long)a->B * ((a->recon_a ? a->A / va : 0) + (a->recon_b ? a->D / vd : 0) + 1);
-    const int grid = mm::grid_for(work, 256 * 4, 2048);
+    static const int wg_cap = getenv("MMVAE_LOSS_WG") ? atoi(getenv("MMVAE_LOSS_WG")) * 256 : 1024;
+    const int grid = mm::grid_for(work, 256 * 4, wg_cap);
 #define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a)
     if (va == 4 && vd == 4) MM_LOSS(4, 4); else if (va == 4 && vd == 2) MM_LOSS(4, 2); else if (va == 4) MM_LOSS(4, 1);
     else if (va == 2 && vd == 4) MM_LOSS(2, 4); else if (va == 2 && vd == 2) MM_LOSS(2, 2); else if (va == 2) MM_LOSS(2, 1);
