@@ -143,8 +143,8 @@ def main():
         opt.step()
         return rec
 
-    # Default on one GPU: the SAME step captured once as a hipGraph (mmvae.graphs) and replayed; the three loss floats
-    # are still read back on the host every step, as the reference's vae_loss does (one 16-byte read after the replay).
+    # Default on one GPU: the SAME step captured once as a hipGraph (mmvae.graphs) and replayed; the loss floats of every
+    # step are still read on the host, as the reference's loop does to log them -- one step behind the launches.
     # N > 1: two graphs, [forward, loss, backward] and [AdamW], with the RCCL all-reduce of the flat gradient arena issued
     # eagerly between the replays (nothing of RCCL is captured).
     graphed = None
@@ -160,8 +160,13 @@ def main():
             graphed = None
 
     def graph_step():
-        graphed()
-        return graphed.losses()[1]
+        # every step's loss floats reach the host, one step behind the launches (GraphedTrainStep.step_logged): the host never
+        # stalls the GPU between two replays.  MMVAE_SYNC_LOSS=1: read them right after each replay instead (A/B switch).
+        if os.environ.get("MMVAE_SYNC_LOSS") == "1":
+            graphed()
+            return graphed.losses()[1]
+        prev = graphed.step_logged()
+        return None if prev is None else prev[1]
 
     step = graph_step if graphed is not None else eager_step
 
@@ -188,6 +193,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    if graphed is not None and os.environ.get("MMVAE_SYNC_LOSS") != "1":
+        last = graphed.flush_logged()[1]          # the last step's losses: read inside the timed region
     fence()
     dt = time.perf_counter() - t0
     if graphed is not None and survey is not None:

@@ -147,6 +147,40 @@ def test_graphed_train_step_matches_eager():
     assert int(o2.state[next(iter(m2.parameters()))]["step"].item()) == n_warm + 1 + n_run
 
 
+def test_graphed_step_logged_is_losses_one_step_late():
+    """GraphedTrainStep.step_logged() (loss floats copied to pinned host memory behind the replay, read one step later)
+    returns exactly what losses() reads right after each replay: same graph, same Philox stream, same parameters."""
+    from mmvae.graphs import GraphedTrainStep
+    A, D, S, L, B = 782, 572, 24, 20, 512
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(B, A, generator=g).abs().to(DEV); b = torch.rand(B, D, generator=g).to(DEV)
+    site = torch.randint(0, S, (B,), generator=g).to(DEV)
+
+    def run(pipelined, n=5):
+        torch.manual_seed(7)
+        m = MultiModalVAE(A, D, S, L).to(DEV).train()
+        engine.GLOBAL_NOISE.offset_tensor(torch.device(DEV, torch.cuda.current_device())).zero_()
+        gs = GraphedTrainStep(m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5), a, b, site, warmup=2)
+        out = []
+        if not pipelined:
+            for _ in range(n):
+                gs(); out.append(gs.losses())
+            return out
+        assert gs.flush_logged() is None
+        for i in range(n):
+            prev = gs.step_logged()
+            assert (prev is None) == (i == 0)
+            if prev is not None:
+                out.append(prev)
+        out.append(gs.flush_logged())
+        return out
+
+    ref, got = run(False), run(True)
+    assert len(got) == len(ref) == 5
+    np.testing.assert_allclose(np.array(got), np.array(ref), rtol=2e-3)        # atomics order: not bitwise
+    assert all(np.isfinite(np.array(got)).ravel())
+
+
 def test_graphed_data_parallel_step_two_graphs(tmp_path):
     """Data-parallel form of the graphed step: [forward, loss, backward] and [AdamW] captured separately, the gradient
     all-reduce issued eagerly in between on the flat arena (one SUM all-reduce).  With a one-rank group the result

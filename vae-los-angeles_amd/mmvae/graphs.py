@@ -103,3 +103,33 @@ class GraphedTrainStep:
     def losses(self):
         """(total, recon, class, kld) as floats: the ONE host read of the step (vae_loss does the same)."""
         return tuple(self.out4.tolist())
+
+    # --- pipelined logging -------------------------------------------------------------------------------------------
+    # `losses()` right after a replay makes the host wait for the step, and the GPU then waits for the host to wake up,
+    # run Python and launch the next graph: ~55 us of idle GPU per 1.9 ms step (rocprofv3 timeline).  The reference loop
+    # reads the loss only to log it (optimize_hyperparameters.py:113-117), so the read can trail the launches by one step:
+    # every replay is followed, on the same stream, by a 16-byte copy into one of two pinned host slots and an event;
+    # `step_logged()` launches step i and THEN waits for the event of step i-1.  Every step's loss still reaches the host.
+    def step_logged(self):
+        """Launch one step; returns the (total, recon, class, kld) floats of the PREVIOUS step (None on the first call)."""
+        if getattr(self, "_pin", None) is None:
+            self._pin = [torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pin_n = 0                                      # steps launched through this method
+        self()
+        k = self._pin_n & 1
+        self._pin[k].copy_(self.out4, non_blocking=True)         # stream-ordered: runs before the next replay overwrites out4
+        self._pin_ev[k].record()
+        self._pin_n += 1
+        if self._pin_n < 2:
+            return None
+        self._pin_ev[k ^ 1].synchronize()
+        return tuple(self._pin[k ^ 1].tolist())
+
+    def flush_logged(self):
+        """Losses of the last step launched by `step_logged()` (waits for it)."""
+        if not getattr(self, "_pin_n", 0):
+            return None
+        k = (self._pin_n - 1) & 1
+        self._pin_ev[k].synchronize()
+        return tuple(self._pin[k].tolist())
