@@ -14,13 +14,22 @@ namespace mm {
 __global__ __launch_bounds__(256) void prep_weights_kernel(const mmvae_prep_item* __restrict__ items) {
     const mmvae_prep_item it = items[blockIdx.y];
     const long total = (long)it.dst_rows * it.dst_cols;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(idx / it.dst_cols), c = (int)(idx % it.dst_cols);
+    auto put = [&](int r, int c) {
         const int sr = it.transpose ? c : r, sc = it.transpose ? r : c;
         float v = (sr < it.src_rows && sc < it.src_cols) ? it.src[(long)sr * it.src_ld + sc] : 0.f;
         if (it.dst_dtype == MMVAE_BF16) ((bf16*)it.dst)[(long)r * it.dst_ld + c] = (bf16)v;
         else ((float*)it.dst)[(long)r * it.dst_ld + c] = v;
+    };
+    if (total < (1L << 31)) {            // 32-bit index math: the 64-bit division per element made this kernel VALU-bound
+        const unsigned cols = (unsigned)it.dst_cols, n = (unsigned)total, nt = gridDim.x * blockDim.x;
+        for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += nt) {
+            const unsigned r = idx / cols;
+            put((int)r, (int)(idx - r * cols));
+        }
+        return;
     }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+        put((int)(idx / it.dst_cols), (int)(idx % it.dst_cols));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -145,22 +154,27 @@ __global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int 
                                                                float* d_b_mu, float* d_w_lv, float* d_b_lv) {
     const int L2 = 2 * L;
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int i = t0; i < S * E; i += nt) {           // dEmb = dT x Wcat
-        const int s = i / E, e = i % E;
+    // the three products are independent: one index space [dEmb | dWcat | db], so their (latency-bound) dot products of
+    // 20-24 terms run side by side instead of one phase after the other
+    const int n0 = S * E, n1 = n0 + L2 * E, n2 = n1 + L2;
+    for (int i = t0; i < n2; i += nt) {
         float acc = 0.f;
-        for (int j = 0; j < L; ++j) acc += dT[s * L2 + j] * w_mu[(long)j * E + e] + dT[s * L2 + L + j] * w_lv[(long)j * E + e];
-        d_emb[i] += acc;
-    }
-    for (int i = t0; i < L2 * E; i += nt) {          // dWcat = dT^T x emb
-        const int j = i / E, e = i % E;
-        float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * emb[(long)s * E + e];
-        if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
-    }
-    for (int j = t0; j < L2; j += nt) {
-        float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += dT[s * L2 + j];
-        if (j < L) d_b_mu[j] += acc; else d_b_lv[j - L] += acc;
+        if (i < n0) {                                    // dEmb = dT x Wcat
+            const int s = i / E, e = i - s * E;
+#pragma unroll 4
+            for (int j = 0; j < L; ++j) acc += dT[s * L2 + j] * w_mu[(long)j * E + e] + dT[s * L2 + L + j] * w_lv[(long)j * E + e];
+            d_emb[i] += acc;
+        } else if (i < n1) {                             // dWcat = dT^T x emb
+            const int k = i - n0, j = k / E, e = k - j * E;
+#pragma unroll 4
+            for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * emb[(long)s * E + e];
+            if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
+        } else {
+            const int j = i - n1;
+#pragma unroll 4
+            for (int s = 0; s < S; ++s) acc += dT[s * L2 + j];
+            if (j < L) d_b_mu[j] += acc; else d_b_lv[j - L] += acc;
+        }
     }
 }
 
@@ -577,7 +591,7 @@ extern "C" int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const floa
                                      const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
                                      float* d_b_lv, void* stream) {
     if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !w_lv || !d_table || !d_emb || !d_w_mu || !d_b_mu || !d_w_lv || !d_b_lv) return MMVAE_ERR_ARG;
-    const int work = S * E > 2 * L * E ? S * E : 2 * L * E;
+    const int work = S * E + 2 * L * E + 2 * L;          // one output element per thread
     hipLaunchKernelGGL(embed_table_bwd_kernel, dim3((work + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
     MM_CHECK_LAUNCH();
     return 0;
