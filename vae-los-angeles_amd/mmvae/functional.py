@@ -39,9 +39,9 @@ class VAEGraphFn(torch.autograd.Function):
         g_lv = None if gs[n_out + 1] is None else gs[n_out + 1].contiguous().float()
         flags = [False] * n_out
         stash = saved.get("loss_grads")
-        if stash is not None and stash.get("scale") is not None:
-            scale = stash["scale"]
-            ops.scale_many(list(stash["g_outs"]) + [stash["g_mu"], stash["g_lv"]], scale)       # one launch, not five
+        if stash is not None and stash.get("armed"):                 # the loss handle's backward ran: its gradients are the stash
+            if stash.get("scale") is not None:                       # None: unit_grad promised by the caller (fused_loss)
+                ops.scale_many(list(stash["g_outs"]) + [stash["g_mu"], stash["g_lv"]], stash["scale"])       # one launch, not five
             for i in range(n_out):
                 sg = stash["g_outs"][i]
                 if sg is None:
@@ -127,7 +127,9 @@ class _LossHandleFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        ctx.stash["scale"] = g.reshape(1).float().contiguous()
+        if not ctx.stash.get("unit_grad"):
+            ctx.stash["scale"] = g.reshape(1).float().contiguous()
+        ctx.stash["armed"] = True
         return (None, None) + (None,) * 16
 
 
@@ -158,14 +160,16 @@ def _tag_of(t):
     return getattr(t, "_mmvae", None) if t is not None else None
 
 
-def fused_loss(terms, beta, gamma, class_weights=None):
+def fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
+    """unit_grad=True: the caller promises to call `total.backward()` with the default gradient of 1 (a captured training step
+    does): the stashed gradients are then used as they are, without the launch that multiplies them by the incoming gradient."""
     if not next(v[0] for v in terms.values() if v is not None).is_cuda:
         raise RuntimeError("the MI355X loss kernel needs CUDA/HIP tensors; there is no CPU fallback")
     with ops.pinned_stream():
-        return _fused_loss(terms, beta, gamma, class_weights)
+        return _fused_loss(terms, beta, gamma, class_weights, unit_grad)
 
 
-def _fused_loss(terms, beta, gamma, class_weights=None):
+def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     """terms: dict with optional entries
          'a': (recon_a, a)  sum-MSE           'b': (recon_b, b)  sum-BCE (clamped logs)
          'c': (logits, site) weighted sum-CE  'kl': (mu, logvar)
@@ -214,7 +218,7 @@ def _fused_loss(terms, beta, gamma, class_weights=None):
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
                      beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv)
         ops.loss_finalize(sums, beta, gamma, out4)
-        stash = {"g_outs": g_outs, "g_mu": g_mu, "g_lv": g_lv, "scale": None}
+        stash = {"g_outs": g_outs, "g_mu": g_mu, "g_lv": g_lv, "scale": None, "unit_grad": bool(unit_grad)}
         if g_mu is None:                       # KL term absent: nothing flows into mu/logvar from this loss
             stash["g_mu"] = torch.zeros(B, saved["logvar"].shape[1], dtype=torch.float32, device=dev)
             stash["g_lv"] = torch.zeros_like(stash["g_mu"])
