@@ -20,9 +20,11 @@ parts = {
     "ce": dict(logits=lg, site=site, g_c=gc),
     "kl": dict(mu=mu, logvar=lv, g_mu=gmu, g_lv=glv),
 }
-parts["all"] = {k: v for p in parts.values() for k, v in p.items()}
+parts["mse+bce"] = {**parts["mse"], **parts["bce"]}
+parts["all"] = {k: v for p in (parts["mse"], parts["bce"], parts["ce"], parts["kl"]) for k, v in p.items()}
 bytes_ = {"mse": B * A * 10, "bce": B * D * 10, "ce": B * S * 8, "kl": B * Lz * 16}
-bytes_["all"] = sum(bytes_.values())
+bytes_["mse+bce"] = bytes_["mse"] + bytes_["bce"]
+bytes_["all"] = bytes_["mse+bce"] + bytes_["ce"] + bytes_["kl"]
 for name, kw in parts.items():
     ts = []
     for _ in range(7):
