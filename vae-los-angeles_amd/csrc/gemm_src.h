@@ -156,8 +156,11 @@ struct SrcBnBwdApply {
         if (tid < TILE) {
             const int c = col0 + tid;
             const bool ok = c < K;
-            aux[tid] = ok ? mean[c] : 0.f; aux[TILE + tid] = ok ? rstd[c] : 0.f;
-            aux[2 * TILE + tid] = ok ? coef[c] : 0.f; aux[3 * TILE + tid] = ok ? coef[K + c] : 0.f; aux[4 * TILE + tid] = ok ? coef[2 * K + c] : 0.f;
+            // P = c0 (d - c1 - (y - mean) rstd c2) = c0 d - ((y - mean) (c0 c2 rstd) + c0 c1): per element one subtraction and two
+            // fused multiply-adds on four per-column constants (the difference y - mean is still formed first: no cancellation)
+            const float c0 = ok ? coef[c] : 0.f;
+            aux[tid] = ok ? mean[c] : 0.f; aux[TILE + tid] = c0;
+            aux[2 * TILE + tid] = ok ? c0 * coef[2 * K + c] * rstd[c] : 0.f; aux[3 * TILE + tid] = ok ? c0 * coef[K + c] : 0.f;
         }
     }
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {          // K % EPC == 0 (hidden widths), rows padded
@@ -178,8 +181,8 @@ struct SrcBnBwdApply {
         const int c = k & (TILE - 1);
 #pragma unroll
         for (int i = 0; i < EPC; ++i) {
-            const float xh = (r.y.get(i) - aux[c + i]) * aux[TILE + c + i];
-            const float v = aux[2 * TILE + c + i] * (r.d.get(i) - aux[3 * TILE + c + i] - xh * aux[4 * TILE + c + i]);
+            const float t = fmaf(r.y.get(i) - aux[c + i], aux[2 * TILE + c + i], aux[3 * TILE + c + i]);
+            const float v = fmaf(aux[TILE + c + i], r.d.get(i), -t);
             o.set(i, ok ? v : 0.f);
         }
     }
