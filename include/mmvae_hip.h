@@ -61,7 +61,7 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
  *   W        prepared operand [ceil128(N)][ceil64(K)] in compute type, ldw % 64 == 0
  *   prologue MMVAE_PRO_BN_RELU_DROP: A is the previous layer's PRE-BatchNorm output (activation
  *            type); the kernel applies relu(A*pro_scale[k]+pro_shift[k]) * keep/(1-p) on the fly
- *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask] or NULL.
+ *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask], bytes 0 or 1 (mmvae_noise), or NULL.
  *   epilogue MMVAE_EPI_STORE    : C = act(acc + bias) (+ C if accumulate); optional per-column
  *                                 (sum, sum of squares) of the stored values, accumulated into
  *                                 stat1/stat2 (BatchNorm batch statistics)

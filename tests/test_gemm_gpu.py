@@ -115,7 +115,11 @@ def test_bn_relu_drop_prologue_and_bwd_epilogues(prec, with_mask):
     W = torch.randn(N, K, generator=g) / np.sqrt(K)
     b = torch.randn(N, generator=g)
     pl = _prep(W.to(DEV), b.to(DEV), prec)
-    h = torch.relu(y * scale + shift) * (mask.float() * inv_keep if with_mask else 1.0)
+    # as the operand loader computes it: inv_keep folded into fp32 scale / shift, ONE fused multiply-add (exact product + one
+    # rounding, emulated in float64), ReLU, times the keep byte -- so both sides round the same values to the compute type
+    ik32 = torch.tensor(inv_keep, dtype=torch.float32)
+    sc32, sh32 = scale * ik32, shift * ik32
+    h = torch.relu((y.double() * sc32.double() + sh32.double()).float()) * (mask.float() if with_mask else 1.0)
     hq = _round(h, prec)
     ref = hq.double() @ _round(W, prec).double().t() + b.double()
     yd = y.to(DEV).to(adt)

@@ -99,7 +99,10 @@ struct SrcBnReluDrop {
     const uint8_t* mask; long ldm; float inv_keep;
     struct Raw { RawVec<CT, EPC> y; uint32_t m[EPC / 4]; };
     __device__ __forceinline__ void init(float* aux, int tid, int) const {
-        for (int i = tid; i < K; i += NTHREADS) { aux[i] = scale[i]; aux[512 + i] = shift[i]; }
+        // relu(y sc + sh) * inv_keep == relu(y (sc inv_keep) + sh inv_keep) for inv_keep > 0: folded here once per workgroup.
+        // The keep bytes (0 or 1, mmvae_noise) then multiply as floats (v_cvt_f32_ubyteN): 4 VALU per element instead of 7 in
+        // the registers->LDS stage, which is VALU-sensitive (see the BatchNorm-backward source below).
+        for (int i = tid; i < K; i += NTHREADS) { aux[i] = scale[i] * inv_keep; aux[512 + i] = shift[i] * inv_keep; }
     }
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {        // K % EPC == 0 (hidden widths)
         const int rc = min(row, M - 1), kc = min(k, K - EPC);
@@ -123,8 +126,7 @@ struct SrcBnReluDrop {
 #pragma unroll
         for (int i = 0; i < EPC; ++i) {
             const float v = fmaxf(r.y.get(i) * aux[kk + i] + aux[512 + kk + i], 0.f);
-            const float keep = ((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu) ? inv_keep : 0.f;
-            o.set(i, v * keep);
+            o.set(i, v * (float)((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu));
         }
     }
     __device__ __forceinline__ void finish_rows(const Raw& r, int row, int k, Chunk<CT>& o, const float* aux) const { finish(r, row, k, o, aux); }
@@ -134,8 +136,7 @@ struct SrcBnReluDrop {
         for (int i = 0; i < EPC; ++i) {
             float sc = ok ? aux[k + i] : 0.f, sh = ok ? aux[512 + k + i] : 0.f;
             float v = fmaxf(r.y.get(i) * sc + sh, 0.f);
-            float keep = ((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu) ? inv_keep : 0.f;
-            o.set(i, v * keep);
+            o.set(i, v * (float)((r.m[i >> 2] >> (8 * (i & 3))) & 0xffu));
         }
     }
 };
