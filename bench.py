@@ -44,7 +44,9 @@ def synth_batch(B, rank, device):
 
 
 def launch_bytes_flops(meta):
-    """Algorithmic HBM bytes and FLOPs of one tagged GEMM launch."""
+    """Algorithmic HBM bytes and FLOPs of one tagged launch (GEMM, or a streaming kernel: bytes given by the wrapper)."""
+    if meta["kind"] == "stream":
+        return meta["bytes"], 0.0
     M, N, K = meta["M"], meta["N"], meta["K"]
     if meta["kind"] == "nt":
         byts = M * K * meta["a_bytes"] + (M * K if meta["pro_mask"] else 0) + M * N * meta["c_bytes"]
@@ -67,19 +69,48 @@ def pmc_traffic(tag, B):
     return None if k is None else k["total_bytes"]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(B, steps):
+    """oracle/torch_ref.py (stock PyTorch fp32: the reference's own op set) on the host cores.  `value` is the headline batch;
+    SURVEY 8(d) also asks for the reference's native batch 32 and for 4096: `points` (a bounded number of steps each)."""
     import torch_ref
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("MMVAE_CPU_THREADS", "16"))))   # the box grants a 16-CPU share per GPU
-    tr = torch_ref.CpuTrainer(A, D, S, L, seed=0)
-    a, b, site = synth_batch(B, 0, "cpu")
-    tr.step(a, b, site)                                        # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(a, b, site)
-    dt = (time.perf_counter() - t0) / steps
-    return dict(value=B / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+
+    def run(bsz, n, warm):
+        tr = torch_ref.CpuTrainer(A, D, S, L, seed=0)
+        a, b, site = synth_batch(bsz, 0, "cpu")
+        for _ in range(warm):
+            tr.step(a, b, site)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(a, b, site)
+        return (time.perf_counter() - t0) / n
+
+    dt = run(B, steps, 1)
+    points = {str(B): dict(ms_per_step=dt * 1e3, samples_per_s=B / dt, steps=steps)}
+    for bsz, n, warm in ((32, 100, 10), (4096, 10, 2)):
+        if bsz != B:
+            d = run(bsz, n, warm)
+            points[str(bsz)] = dict(ms_per_step=d * 1e3, samples_per_s=bsz / d, steps=n)
+    return dict(value=B / dt, unit="samples/s", cores=torch.get_num_threads(), cpu=cpu_model(), kind="port", points=points,
                 sample=f"{steps} full training steps (after 1 warm-up) of oracle/torch_ref.py, stock PyTorch fp32, batch {B}, "
-                       f"same synthetic workload; {dt * 1e3:.0f} ms/step")
+                       f"same synthetic workload; {dt * 1e3:.0f} ms/step; `points`: the same step at batch 32 (100 steps) and 4096 (10 steps)")
+
+
+def load_expectations():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_expect.json")))
+    except OSError:
+        return None
 
 
 def main():
@@ -143,6 +174,24 @@ def main():
         opt.step()
         return rec
 
+    # Step 0, eager and CHECKED: fresh seed-0 weights, Philox offset 0 -> the total loss must be the stored expectation
+    # (tests/golden/bench_expect.json; tied to the CPU oracle by tests/test_fullsize_gpu.py).  A wrong kernel cannot hide
+    # behind "the loss is not NaN".
+    expect = load_expectations() if (B == 65536 and args.precision == "bf16" and not dp and (A, D, S, L) == (782, 572, 24, 20)) else None
+    steps_done = 0
+    checks = {}
+    if expect is not None:
+        ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+        loss0, rec0, _, _ = vae_loss(ra, a, rb, b, rc, site, mu, lv, beta=1e-3, gamma=1.0)
+        opt.zero_grad(); loss0.backward(); opt.step()
+        steps_done += 1
+        first = float(loss0.item())
+        rel = abs(first - expect["first_step_total"]) / expect["first_step_total"]
+        checks["first_step_total"] = dict(got=first, recon=rec0, expected=expect["first_step_total"], rel_err=rel, rtol=expect["rtol_first"])
+        if not rel <= expect["rtol_first"]:
+            raise SystemExit(f"first-step loss {first} differs from the stored expectation {expect['first_step_total']} by {rel:.2e}")
+        del ra, rb, rc, mu, lv, loss0
+
     # Default on one GPU: the SAME step captured once as a hipGraph (mmvae.graphs) and replayed; the loss floats of every
     # step are still read on the host, as the reference's loop does to log them -- one step behind the launches.
     # N > 1: two graphs, [forward, loss, backward] and [AdamW], with the RCCL all-reduce of the flat gradient arena issued
@@ -153,6 +202,7 @@ def main():
         reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if dp else None
         try:
             graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2, reduce=reduce)
+            steps_done += 2
         except Exception as exc:                                 # every rank runs the same code: all of them fall back together
             if not dp:
                 raise
@@ -177,18 +227,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    steps_done += args.warmup
     # untimed survey pass: every tagged GEMM launch bracketed by events, to find the dominant one
     probe = survey = None
     if not args.no_probe:
         survey = ops.PROBE = ops.KernelProbe()
         for _ in range(3):
             eager_step()                          # events need eager launches (a captured graph has no Python in it)
+        steps_done += 3
         torch.cuda.synchronize()
         ssum = survey.summary()
         dom_tag = max(ssum, key=lambda t: ssum[t]["mean_ms"] * ssum[t]["calls"])
+        gemm_tags = [t for t in ssum if ssum[t]["meta"]["kind"] != "stream"]
+        dom_gemm = max(gemm_tags, key=lambda t: ssum[t]["mean_ms"] * ssum[t]["calls"])
         # timed region: only the dominant launch is bracketed (2 events per step); under graph replay no Python runs,
         # so the dominant launch is timed in a separate eager pass right after the timed region instead
-        probe = ops.PROBE = ops.KernelProbe(only={dom_tag}) if graphed is None else None
+        probe = ops.PROBE = ops.KernelProbe(only={dom_tag, dom_gemm}) if graphed is None else None
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,8 +251,21 @@ def main():
         last = graphed.flush_logged()[1]          # the last step's losses: read inside the timed region
     fence()
     dt = time.perf_counter() - t0
+    steps_done += args.steps
+    # the last timed step's reconstruction loss against the stored trajectory value for exactly this many steps (default flags)
+    if expect is not None and graphed is not None:
+        want = expect.get("after_steps", {}).get(str(steps_done))
+        if want is not None:
+            rel = abs(last - want["recon"]) / want["recon"]
+            checks["last_step_recon"] = dict(got=last, expected=want["recon"], rel_err=rel, rtol=want["rtol"], after_steps=steps_done)
+            if not rel <= want["rtol"]:
+                raise SystemExit(f"reconstruction loss after {steps_done} steps: {last}, stored expectation {want['recon']} (rel {rel:.2e})")
+        else:
+            checks["last_step_recon"] = dict(got=last, expected=None, after_steps=steps_done)
+        if not last < checks["first_step_total"]["recon"]:
+            raise SystemExit("the loss did not go down during the benchmark")
     if graphed is not None and survey is not None:
-        probe = ops.PROBE = ops.KernelProbe(only={dom_tag})
+        probe = ops.PROBE = ops.KernelProbe(only={dom_tag, dom_gemm})
         for _ in range(args.steps):
             eager_step()
         torch.cuda.synchronize()
@@ -222,39 +289,50 @@ def main():
                    "grad_allreduce": (None if not dp else "RCCL SUM over the flat fp32 gradient arena, between the two graph replays" if graphed is not None
                                       else "RCCL SUM over flat fp32 arena, decoder bucket overlapped with encoder backward"),
                    "launch": ("eager (Python-issued launches)" if graphed is None else
-                              "hipGraph replay (1 launch/step)" if not dp else "2 hipGraph replays/step around the eager all-reduce")},
+                              "hipGraph replay (1 launch/step)" if not dp else "2 hipGraph replays/step around the eager all-reduce"),
+                   "loss_logging": ("every step's [total, recon, class, kld] reaches the host, as optimize_hyperparameters.py:113 reads it, but ONE STEP "
+                                    "LATE (pinned 20-byte copy behind each replay; the last step's is read inside the timed region)"
+                                    if (graphed is not None and os.environ.get("MMVAE_SYNC_LOSS") != "1") else "read right after each step")},
+        "checks": checks,
         "step_tflops": FLOPS_PER_SAMPLE * B / (ms * 1e-3) / 1e12,
         "step_mfma_frac": FLOPS_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.precision],
     }
     if rank == 0:
         if probe is not None:
             summ = ssum
-            summ.update(probe.summary())         # the dominant launch: timed-region measurement
+            summ.update(probe.summary())         # the dominant launches: timed-region measurement
             kernels = []
             for tag, s in summ.items():
                 byts, flops = launch_bytes_flops(s["meta"])
-                per_step_ms = s["mean_ms"] * s["calls"] / (args.steps if tag == dom_tag else 3)
+                per_step_ms = s["mean_ms"] * s["calls"] / (args.steps if tag in (dom_tag, dom_gemm) else 3)
                 kernels.append(dict(tag=tag, ms=s["mean_ms"], per_step_ms=per_step_ms, GBs=byts / s["mean_ms"] / 1e6,
                                     TFLOPs=flops / s["mean_ms"] / 1e9, bytes=byts, flops=flops))
             kernels.sort(key=lambda k: -k["per_step_ms"])
-            dom = kernels[0]
-            t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
-            t_mfma = dom["flops"] / (MFMA_PEAK_TFLOPS[args.precision] * 1e12)
-            if t_hbm >= t_mfma:
-                out["roofline"] = {"bound": "hbm", "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["tag"], B) if args.precision == "bf16" else None, "kernel": dom["tag"],
-                                   "launch_ms": dom["ms"], "algorithmic_bytes": dom["bytes"]}
-            else:
-                out["roofline"] = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": MFMA_PEAK_TFLOPS[args.precision],
-                                   "unit": "TFLOP/s", "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": pmc_traffic(dom["tag"], B) if args.precision == "bf16" else None,
-                                   "kernel": dom["tag"], "launch_ms": dom["ms"], "algorithmic_flops": dom["flops"]}
-            out["roofline"]["definition"] = ("largest single GEMM launch of the step; duration = HIP events on the launch stream around that "
-                                             "launch over the timed steps (eager pass), bytes = algorithmic operand + result bytes of the launch")
+
+            def roof(dom, definition):
+                t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+                t_mfma = dom["flops"] / (MFMA_PEAK_TFLOPS[args.precision] * 1e12)
+                traffic = pmc_traffic(dom["tag"], B) if args.precision == "bf16" else None
+                if t_hbm >= t_mfma:
+                    r = {"bound": "hbm", "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBs"] / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": dom["tag"], "launch_ms": dom["ms"], "algorithmic_bytes": dom["bytes"]}
+                else:
+                    r = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": dom["TFLOPs"] / MFMA_PEAK_TFLOPS[args.precision], "traffic": traffic, "kernel": dom["tag"],
+                         "launch_ms": dom["ms"], "algorithmic_flops": dom["flops"]}
+                r["definition"] = definition
+                return r
+            how = ("duration = HIP events on the launch stream around that launch over the timed steps (eager pass), bytes = algorithmic "
+                   "operand + result bytes of the launch")
+            out["roofline"] = roof(next(k for k in kernels if k["tag"] == dom_tag), "largest single launch of the step, any kind; " + how)
+            out["roofline_gemm"] = roof(next(k for k in kernels if k["tag"] == dom_gemm), "largest single GEMM launch of the step; " + how)
             # the same figure per kernel SYMBOL (what rocprofv3 --stats lists): launches grouped by the template instantiation they select
             fam = {}
             for k in kernels:
                 m = summ[k["tag"]]["meta"]
-                if m["kind"] == "nt":
+                if m["kind"] == "stream":
+                    name = k["tag"].split(".")[0]
+                elif m["kind"] == "nt":
                     name = (f"gemm_nt<{'f32' if m['a_bytes'] == 4 else 'bf16'} A{'+BN' if m.get('pro') else ''}, "
                             f"{('store', 'relu-mask', 'bn-bwd')[m['epi']]}, {'f32' if m['c_bytes'] == 4 else 'bf16'} C, {'128x256' if m['N'] % 256 == 0 else '128x128'}>")
                 else:
@@ -267,7 +345,8 @@ def main():
                                          "achieved": top["bytes"] / top["ms_per_step"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": top["bytes"] / top["ms_per_step"] / 1e6 / HBM_PEAK_GBS,
                                          "TFLOPs": top["flops"] / top["ms_per_step"] / 1e9}
-            out["gemm_ms_per_step"] = sum(k["per_step_ms"] for k in kernels)
+            out["gemm_ms_per_step"] = sum(k["per_step_ms"] for k in kernels if summ[k["tag"]]["meta"]["kind"] != "stream")
+            out["probed_ms_per_step"] = sum(k["per_step_ms"] for k in kernels)
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items() if k not in ("bytes", "flops")}
                               for kk in kernels[:40]]
         if world == 1 and args.cpu_steps > 0:

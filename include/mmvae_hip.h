@@ -131,15 +131,20 @@ typedef struct {
     float* mean; float* rstd; float* scale; float* shift;
 } mmvae_bn_finalize_args;
 int mmvae_bn_finalize(const mmvae_bn_finalize_args* args, void* stream);
+/* eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; optionally (non-NULL) also
+ * mean = running_mean and rstd = 1 / sqrt(running_var + eps), which a backward pass through an eval-mode forward needs. */
 int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* beta, const float* running_mean,
-                         const float* running_var, float eps, float* scale, float* shift, void* stream);
+                         const float* running_var, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream);
 
 /* BatchNorm backward reductions: from the sums (sum d, sum d*xhat) of MMVAE_EPI_BN_BWD phase 0:
- *   dgamma += sum d*xhat ; dbeta += sum d ; coef[3][N] = {gamma*rstd, dbeta/M, dgamma/M}   */
+ *   dgamma += sum d*xhat ; dbeta += sum d ; coef[3][N] = {gamma*rstd, dbeta/M, dgamma/M}
+ * eval_mode != 0 (the forward ran on the running statistics, torch's batch_norm(training=False) backward): the
+ * normalisation does not depend on the batch, coef = {gamma*rstd, 0, 0}; dgamma / dbeta as above. */
 typedef struct {
     int32_t M, N; const double* sum_d; const double* sum_dx;      /* [N] each, from MMVAE_EPI_BN_BWD phase 0 */
     const float* gamma; const float* rstd;
     float* dgamma; float* dbeta; float* coef;           /* coef: [3][N] */
+    int32_t eval_mode;
 } mmvae_bn_bwd_finalize_args;
 int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* args, void* stream);
 /* d <- coef0 * (d - coef1 - xhat*coef2), xhat = (y-mean)*rstd, in place on the activation-typed buffer d written by
@@ -193,7 +198,11 @@ int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* args, void* stream);
  *   sums[1] += sum -[b*max(log p,-100) + (1-b)*max(log(1-p),-100)]   (losses.py:34)
  *   sums[2] += sum_i w[site_i] * nll_i                          (losses.py:39)
  *   sums[3] += -0.5 * sum(1 + lv - mu^2 - exp(lv))              (losses.py:42)
- * `sums` is double[4], zeroed by the caller.  Gradients of total = s0+s1+gamma*s2+beta*s3:
+ *   sums[4] += number of labels outside [0, S)  (torch's cross_entropy device-asserts on them; here such a row is
+ *              computed as class 0 and COUNTED: the host wrapper raises when the count it reads back is not 0)
+ * `sums` is double[5], zeroed by the caller.  out5 / ticket (both or neither; ticket is one zeroed uint32): the block that
+ * finishes last writes out5 = {s0+s1 + gamma*s2 + beta*s3, s0+s1, s2, s3, s4} as floats (the tuple of losses.py:44,46) and
+ * re-arms the ticket -- no separate mmvae_loss_finalize launch.  Gradients of total = s0+s1+gamma*s2+beta*s3:
  *   g_a = 2(recon_a-a) ; g_b = (p-b)/max(p(1-p),1e-12)  [grad_b_wrt_logit: times p(1-p)] ;
  *   g_c = gamma*w[y]*(softmax - onehot) ; g_mu = beta*mu ; g_lv = -0.5*beta*(1-exp(lv)).
  * ------------------------------------------------------------------------------------------- */
@@ -209,10 +218,11 @@ typedef struct {
     void* g_b; int32_t g_b_dtype; int64_t ld_gb; int32_t grad_b_wrt_logit;
     float* g_c; int64_t ld_gc;
     float* g_mu; float* g_lv;
+    float* out5; uint32_t* ticket;
 } mmvae_loss_args;
 int mmvae_vae_loss(const mmvae_loss_args* args, void* stream);
-/* out4 = {recon + gamma*class + beta*kld, recon, class, kld} (float), the tuple losses.py:44,46 returns. */
-int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out4, void* stream);
+/* out5 = {recon + gamma*class + beta*kld, recon, class, kld, bad labels} (float) from sums[5]: stand-alone form of the tail. */
+int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out5, void* stream);
 
 /* out = g * p * (1-p): Sigmoid backward for gradients that arrive w.r.t. recon_b (decoders.py:32). */
 int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,
@@ -231,10 +241,11 @@ int mmvae_scale_many(const mmvae_scale_item* items_host, int32_t n_items, const 
  * (torch.randn_like, vae.py:14).
  * ------------------------------------------------------------------------------------------- */
 /* One launch: n_mask keep-mask bytes (P(1) = keep_prob) and n_eps standard normals.  The Philox counter starts at
- * offset + *offset_dev (offset_dev may be NULL); a device-resident offset advanced by mmvae_counter_add lets a captured
- * hipGraph draw fresh noise on every replay.  The call consumes ceil(n_mask/16)*4 + ceil(n_eps/4) counter values. */
+ * offset + *offset_dev (offset_dev may be NULL); a device-resident offset lets a captured hipGraph draw fresh noise on
+ * every replay.  The call consumes ceil(n_mask/16)*4 + ceil(n_eps/4) counter values; with advance_ticket != NULL (one
+ * zeroed uint32 next to the counter) the launch itself adds that amount to *offset_dev once all its blocks have read it. */
 int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed, uint64_t offset,
-                const uint64_t* offset_dev, void* stream);
+                uint64_t* offset_dev, uint32_t* advance_ticket, void* stream);
 int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /* *counter_dev += inc */
 
 /* ---------------------------------------------------------------------------------------------
@@ -246,9 +257,10 @@ int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } mmvae_adamw_item;
 int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                     const uint64_t* step_dev, void* stream);
-/* step_dev != NULL: bias corrections are computed in the kernel from t = *step_dev + 1 (graph-capturable; advance the
- * counter with mmvae_counter_add after the launch) and bias_corr1/2 are ignored. */
+                     uint64_t* step_dev, uint32_t* advance_ticket, void* stream);
+/* step_dev != NULL: bias corrections are computed in the kernel from t = *step_dev + 1 (graph-capturable) and
+ * bias_corr1/2 are ignored.  advance_ticket != NULL (one zeroed uint32; n_items <= 64): the launch increments *step_dev
+ * itself once every block has read it; otherwise advance the counter with mmvae_counter_add after the launch. */
 
 #ifdef __cplusplus
 }

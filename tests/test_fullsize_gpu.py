@@ -1,0 +1,123 @@
+"""The headline size, CHECKED: one full training step at B = 65 536 (BASELINE.json configs[2], the bench workload) in both
+precision modes against the CPU oracle on the same seeded inputs and injected noise.
+
+  fp32 mode: against the reference arithmetic (np_oracle, fp64)          -- outputs 5e-5, four loss terms 2e-5 rel,
+             every gradient 1e-3 Frobenius-rel / 2e-2 scaled max, BatchNorm running statistics, parameters after AdamW.
+  bf16 mode: against the bf16-aware oracle (np_oracle, q=BF16)           -- outputs 5e-3, loss terms 1e-4 rel, every gradient
+             1e-2 Frobenius-rel / 2e-2 scaled max (TOL_Q);
+             against the reference arithmetic the loss terms hold 3e-3 rel (reported with the gradient deviation).
+What first bites at this size and is covered here: 32-bit offset limits of the operand loaders (205 MB operands), 512-way
+batch splits of the dW GEMMs and their slab reduce, f64-atomic statistics over 65 536 rows, the full-line epilogue paths.
+
+Plus the bench configuration itself (torch.manual_seed(0) weights, bench.synth_batch, device Philox noise): its first-step
+loss against oracle/torch_ref.py on the host (stock torch, its own dropout RNG: the noise realisation is the tolerance),
+which is what ties tests/golden/bench_expect.json -- the values bench.py asserts -- to the oracle.
+The numpy oracle needs ~5 s per run at this size on the box's host cores (~40 s on 8 slower ones).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import np_oracle as O  # noqa: E402
+from model_util import load_state, masks_list, f64  # noqa: E402
+from test_model_gpu import oracle_step, compare_step, TOL, tol_q, report, t  # noqa: E402
+from mmvae import engine  # noqa: E402
+from mmvae.optim import FusedAdamW  # noqa: E402
+from src.models import MultiModalVAE  # noqa: E402
+from src.utils import vae_loss  # noqa: E402
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A, D, S, L, E, B = 782, 572, 24, 20, 32, 65536
+
+
+@pytest.fixture(scope="module")
+def case():
+    P, Bf = O.make_params(4242, A, D, S, L, E)
+    a, b, site = O.make_batch(4243, B, A, D, S)
+    masks, eps = O.make_noise(4244, B, L)
+    return dict(P=P, Bf=Bf, a=a, b=b, site=site, masks=masks, eps=eps, P64=f64(P), Bf64=f64(Bf), ref={})
+
+
+def _oracle(case, q):
+    key = "q" if q is not None else "f"
+    if key not in case["ref"]:
+        case["ref"][key] = oracle_step(case["P64"], case["Bf64"], case["a"], case["b"], case["site"], case["masks"], case["eps"],
+                                       1e-3, 1.0, None, q)
+    return case["ref"][key]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_step_at_batch_65536(case, prec):
+    model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), case["P"], case["Bf"]).to(DEV).set_precision(prec).train()
+    opt = FusedAdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
+    a, b, site = t(case["a"]), t(case["b"]), t(case["site"])
+    engine.GLOBAL_NOISE.inject(masks_list(case["masks"]), torch.from_numpy(case["eps"]))
+    ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+    loss, rec, cls, kld = vae_loss(ra, a, rb, b, rc, site, mu, lv, beta=1e-3, gamma=1.0)
+    engine.GLOBAL_NOISE.clear()
+    opt.zero_grad()
+    loss.backward()
+    outs, losses = (ra, rb, rc, mu, lv), (loss.item(), rec, cls, kld)
+    ref = _oracle(case, None)
+    if prec == "fp32":
+        # max-norm: ONE ReLU flip against the fp64 oracle (a pre-activation within an fp32 ulp of zero; ~10 expected among the
+        # 59 M of this batch) toggles one sample's whole contribution to a weight-gradient row, which is a sum of 65 536
+        # random-sign terms: 1 / sqrt(65 536) = 4e-3 of its scale per flip.  The Frobenius bound stays at 1e-3.
+        e = compare_step(model, outs, losses, ref, dict(TOL["fp32"], grad=2e-2))
+    else:
+        e = compare_step(model, outs, losses, _oracle(case, O.BF16), tol_q(B))
+        report(f"B=65536 prec=bf16 vs bf16-aware oracle: out {e['out']:.3e}; loss rel {e['loss']:.3e}; grad max scaled {e['grad']:.3e} "
+               f"({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")
+        e = compare_step(model, outs, losses, ref, TOL["bf16"])
+    report(f"B=65536 prec={prec} vs fp64 reference arithmetic: out {e['out']:.3e}; loss rel {e['loss']:.3e}; grad max scaled {e['grad']:.3e} "
+           f"({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")
+    # AdamW on top (first step: p -= lr * sign-ish(g)): parameters after the step against the oracle's update of ITS gradients
+    G = (ref if prec == "fp32" else _oracle(case, O.BF16))["G"]
+    P1 = {k: v.copy() for k, v in case["P64"].items()}
+    st, step = O.adamw_init(P1)
+    O.adamw_step(P1, G, st, step, lr=5e-4, wd=1e-5)
+    opt.step()
+    from model_util import CHAOTIC_BIASES
+    for k, p in model.named_parameters():
+        if k in CHAOTIC_BIASES:
+            continue
+        d = np.abs(p.detach().cpu().numpy() - P1[k])
+        # a first Adam step moves every element by ~lr; elements whose gradient is rounding noise may take the other sign
+        assert np.mean(d > 1e-6) <= (2e-3 if prec == "fp32" else 2e-2) and d.max() <= 2.1 * 5e-4, (k, float(d.max()), float(np.mean(d > 1e-6)))
+
+
+def test_bench_configuration_first_step_vs_cpu_reference():
+    """bench.py's own workload: seed-0 torch init, bench.synth_batch, Philox noise on the device.  The first-step loss terms
+    against oracle/torch_ref.py with the SAME weights and batch (torch's own dropout / eps draws): agreement to the noise
+    realisation (the sums run over 65 536 x 782 / 572 terms) -- and the stored expectation bench.py asserts is the same value."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch_ref as T
+    dev = torch.device(DEV, torch.cuda.current_device())
+    torch.manual_seed(0)
+    model = MultiModalVAE(A, D, S, L).to(DEV).set_precision("bf16").train()
+    a, b, site = bench.synth_batch(B, 0, DEV)
+    engine.GLOBAL_NOISE.offset_tensor(dev).zero_()
+    ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+    loss, rec, cls, kld = vae_loss(ra, a, rb, b, rc, site, mu, lv, beta=1e-3, gamma=1.0)
+    p = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    bufs = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
+    for k in bufs:                                   # the forward above already updated the running statistics: irrelevant in train mode
+        pass
+    torch.manual_seed(1)
+    with torch.no_grad():
+        ra_, rb_, rc_, mu_, lv_ = T.forward(p, bufs, a.cpu(), b.cpu(), site.cpu(), True)
+        tot_, rec_, cls_, kld_ = T.loss_fn(ra_, a.cpu(), rb_, b.cpu(), rc_, site.cpu(), mu_, lv_, 1e-3, 1.0)
+    got, want = np.array([loss.item(), rec, cls, kld]), np.array([tot_.item(), rec_.item(), cls_.item(), kld_.item()])
+    report(f"bench configuration first step: GPU bf16 {got.tolist()} vs torch_ref fp32 {want.tolist()}")
+    np.testing.assert_allclose(got[:3], want[:3], rtol=3e-3)
+    np.testing.assert_allclose(got[3], want[3], rtol=2e-2)                       # KL: a small difference of O(1) terms, noise-sensitive
+    exp = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_expect.json")))
+    np.testing.assert_allclose(got[0], exp["first_step_total"], rtol=exp["rtol_first"])

@@ -13,6 +13,9 @@ Stated tolerances (max abs error relative to the tensor's max abs, "scaled error
              oracle, which switches that sample's whole gradient contribution on or off
              (reproduced on the CPU by rounding ONLY that tensor to bf16: 0.12 scaled / 0.037
              Frobenius on encoder_a.fc.0.weight).  It is zero-mean noise, not a bias.
+That deviation from the fp64 reference arithmetic is therefore only REPORTED and loosely bounded; what pins the bf16 kernels
+is the bf16-aware oracle (np_oracle with q=BF16: the engine's rounding points restated on the CPU): against it bf16
+gradients hold <= 1e-2 Frobenius-relative / <= 2e-2 scaled max per tensor (TOL_Q), as SURVEY 8(d) asks.
 The measured values are written to gpurun_out/parity_report.txt and quoted in DESIGN.md.
 """
 import os
@@ -144,14 +147,92 @@ def test_directional_vs_golden_fp32(kind):
             continue
         expect(fx, "final." + kname, v.cpu().numpy(), 1e-4, 3e-4 if kname.endswith("running_mean") else 2e-6,
                outlier_frac=2e-3, outlier_atol=1.1 * 5e-4)
+    # site=None inference (reconstruct_unmatched.py:193) on the HIP path, eval mode, with the chaotic tensors adopted
+    with torch.no_grad():
+        st = model.state_dict()
+        for kname in st:
+            top, rest = kname.split(".", 1)
+            if inv[top] + "." + rest in CHAOTIC_BIASES or kname.endswith("running_mean"):
+                st[kname].copy_(t(fx["final." + kname]))
+    model.eval()
+    with torch.no_grad():
+        engine.GLOBAL_NOISE.inject([], torch.from_numpy(eps))
+        rec, mu, lv = model(rna=a) if kind == "rna2dna" else model(dna=b)
+        engine.GLOBAL_NOISE.clear()
+    expect(fx, "eval.nosite.out", rec.cpu().numpy(), 5e-4, 1e-4)
+    expect(fx, "eval.nosite.mu", mu.cpu().numpy(), 5e-4, 1e-4)
+    assert model(None, None) == (None, None, None)
 
 
 # ----------------------------------------------------------------------------------------------
 # (2) numpy oracle at larger batches, both precisions, measured error report
 # ----------------------------------------------------------------------------------------------
+# Tolerances against the bf16-AWARE oracle (np_oracle with q=BF16: the same roundings the engine applies, fp64 in between).
+# What is left is fp32-vs-fp64 accumulation: a stored bf16 value lands on the neighbouring bf16 number when the fp32 sum and the
+# fp64 sum straddle a rounding boundary (~5e-4 of all elements: |sum error| ~ 1e-6 against a bf16 spacing of 4..8e-3).  One ulp
+# of a hidden activation is <= 2.8e-3 of an output's scale (`out`, max-norm); ~0.5 % of those elements sit close enough to zero
+# to flip the ReLU behind them, and ONE flip toggles one sample's whole contribution to a gradient row, i.e. ~1/sqrt(B) of that
+# row's scale in max-norm (`grad`: 2e-2 as SURVEY 8(d) asks from B = 4096 up, 4/sqrt(B) below) while the Frobenius error stays
+# under 1e-2 at every size.
+TOL_Q = dict(out=5e-3, loss=1e-4, fro=1e-2, grad=2e-2)
+
+
+def tol_q(B):
+    return dict(TOL_Q, grad=max(TOL_Q["grad"], 4.0 / np.sqrt(B)))
+
+
+def oracle_step(P64, Bf64, a, b, site, masks, eps, beta, gamma, cw, q):
+    """One forward + loss + backward of the numpy oracle (q=None: reference arithmetic; q=O.BF16: bf16-aware)."""
+    f = np.float64
+    Bf_run = dict(Bf64)
+    oa, ob, oc, mu, lv, cache = O.vae_forward(P64, Bf_run, a.astype(f), b.astype(f), site, masks, eps.astype(f), True, q=q)
+    tot, rec, cls, kld, g = O.vae_loss(oa, a.astype(f), ob, b.astype(f), oc, site, mu, lv, beta, gamma,
+                                       None if cw is None else cw.astype(f), q=q)
+    if q is None:
+        G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b"], g["recon_c"], g["mu"], g["logvar"])
+    else:
+        G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b_logit"], g["recon_c"], g["mu"], g["logvar"], q, True)
+    return dict(out_a=oa, out_b=ob, out_c=oc, mu=mu, logvar=lv, losses=(tot, rec, cls, kld), G=G, Bf=Bf_run)
+
+
+def compare_step(model, outs, losses, ref, tol, zero_scale_key="encoder_b.fc.0.weight"):
+    """-> dict of measured errors; asserts them against `tol` (keys out, loss, fro, grad) after measuring ALL of them (the
+    measured values go to the parity report even when an assertion fires)."""
+    errs = {}
+    for nm, got in zip(("out_a", "out_b", "out_c", "mu", "logvar"), outs):
+        errs[nm] = scaled_err(got.detach().cpu().numpy(), ref[nm])
+    lerr = max(abs(g_ - r_) / abs(r_) for g_, r_ in zip(losses, ref["losses"]))
+    G = ref["G"]
+    gerr, gfro, zero_bias = {}, {}, {}
+    for k, gv in named_grads(model).items():
+        if k in CHAOTIC_BIASES:          # analytically zero (a bias in front of BatchNorm): rounding noise on both sides,
+            # bounded against the scale of the same layer's weight gradient
+            zero_bias[k] = float(np.max(np.abs(gv - G[k]))) / float(np.max(np.abs(G[k.replace(".bias", ".weight")])))
+            continue
+        gerr[k] = scaled_err(gv, G[k])
+        gfro[k] = float(np.linalg.norm(gv - G[k]) / np.linalg.norm(G[k]))
+    sd = model.state_dict()
+    berr = {k: scaled_err(sd[k].cpu().numpy(), v) for k, v in ref["Bf"].items() if k.endswith("running_mean") or k.endswith("running_var")}
+    e = dict(out=max(errs.values()), loss=lerr, grad=max(gerr.values()), grad_worst=max(gerr, key=gerr.get),
+             fro=max(gfro.values()), fro_worst=max(gfro, key=gfro.get), bn=max(berr.values()))
+    report(f"    measured against tol {tol}: {e}")
+    for nm, v in errs.items():
+        assert v <= tol["out"], (nm, v)
+    assert lerr <= tol["loss"], (lerr, losses, ref["losses"])
+    for k, v in zero_bias.items():
+        assert v <= 3e-2, (k, v)
+    for k in gerr:
+        assert gerr[k] <= tol["grad"] and gfro[k] <= tol["fro"], (k, gerr[k], gfro[k])
+    for k, v in berr.items():
+        assert v <= tol["out"], (k, v)
+    return e
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B", [1000, 4096])
 def test_step_vs_oracle(prec, B):
+    """fp32 mode against the reference arithmetic (fp64 oracle); bf16 mode against the bf16-aware oracle at the TIGHT
+    tolerance (TOL_Q) and, as a reported + loosely bounded number, against the fp64 oracle."""
     A, D, S, L, E = 782, 572, 24, 20, 32
     seed = 100 + B
     P, Bf = O.make_params(seed, A, D, S, L, E)
@@ -160,11 +241,6 @@ def test_step_vs_oracle(prec, B):
     cw = np.random.default_rng(5).uniform(0.5, 2.0, S).astype(np.float32)
     beta, gamma = 1e-3, 1.0
     P64, Bf64 = f64(P), f64(Bf)
-    oa, ob, oc, mu, lv, cache = O.vae_forward(P64, Bf64, a.astype(np.float64), b.astype(np.float64), site, masks,
-                                              eps.astype(np.float64), True)
-    tot, rec, cls, kld, g = O.vae_loss(oa, a.astype(np.float64), ob, b.astype(np.float64), oc, site, mu, lv, beta, gamma,
-                                       cw.astype(np.float64))
-    G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b"], g["recon_c"], g["mu"], g["logvar"])
 
     model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), P, Bf).to(DEV).set_precision(prec)
     model.train()
@@ -173,28 +249,16 @@ def test_step_vs_oracle(prec, B):
     loss, r_, c_, k_ = vae_loss(ra, t(a), rb, t(b), rc, t(site), m_, l_, beta=beta, gamma=gamma, class_weights=t(cw))
     engine.GLOBAL_NOISE.clear()
     loss.backward()
-    tol = TOL[prec]
-    errs = {}
-    for nm, got, ref in (("out_a", ra, oa), ("out_b", rb, ob), ("out_c", rc, oc), ("mu", m_, mu), ("logvar", l_, lv)):
-        errs[nm] = scaled_err(got.detach().cpu().numpy(), ref)
-        assert errs[nm] <= tol["out"], (nm, errs[nm])
-    lerr = max(abs(loss.item() - tot) / abs(tot), abs(r_ - rec) / abs(rec), abs(c_ - cls) / abs(cls), abs(k_ - kld) / abs(kld))
-    assert lerr <= tol["loss"], lerr
-    gerr, gfro = {}, {}
-    for k, gv in named_grads(model).items():
-        if k in CHAOTIC_BIASES:
-            assert float(np.max(np.abs(gv))) <= 1e-2 * float(np.max(np.abs(G["encoder_b.fc.0.weight"]))) + 1e-3
-            continue
-        gerr[k] = scaled_err(gv, G[k])
-        gfro[k] = float(np.linalg.norm(gv - G[k]) / np.linalg.norm(G[k]))
-        assert gerr[k] <= tol["grad"] and gfro[k] <= tol["fro"], (k, gerr[k], gfro[k])
-    for k in Bf:
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            got = model.state_dict()[k].cpu().numpy()
-            assert scaled_err(got, Bf64[k]) <= tol["out"], k
-    report(f"step_vs_oracle prec={prec} B={B}: out max scaled err {max(errs.values()):.3e} ({errs}); "
-           f"loss rel err {lerr:.3e}; grad max scaled err {max(gerr.values()):.3e} (worst {max(gerr, key=gerr.get)}); "
-           f"grad max Frobenius-rel err {max(gfro.values()):.3e} (worst {max(gfro, key=gfro.get)})")
+    outs, losses = (ra, rb, rc, m_, l_), (loss.item(), r_, c_, k_)
+    ref = oracle_step(P64, Bf64, a, b, site, masks, eps, beta, gamma, cw, None)
+    e = compare_step(model, outs, losses, ref, TOL[prec])
+    report(f"step_vs_oracle prec={prec} B={B} vs fp64 reference arithmetic: out {e['out']:.3e}; loss rel {e['loss']:.3e}; "
+           f"grad max scaled {e['grad']:.3e} ({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")
+    if prec == "bf16":
+        refq = oracle_step(P64, Bf64, a, b, site, masks, eps, beta, gamma, cw, O.BF16)
+        e = compare_step(model, outs, losses, refq, tol_q(B))
+        report(f"step_vs_oracle prec=bf16 B={B} vs bf16-aware oracle:        out {e['out']:.3e}; loss rel {e['loss']:.3e}; "
+               f"grad max scaled {e['grad']:.3e} ({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -157,3 +157,32 @@ def test_batchnorm_needs_two_rows():
 def test_no_modalities_returns_nones():
     P, Bf = O.make_params(1, 8, 8, 3, 2, 4)
     assert O.vae_forward(P, Bf) == (None,) * 6
+
+
+def test_eval_mode_backward_matches_autograd():
+    """Backward THROUGH an eval-mode forward (BatchNorm on running statistics, no dropout: fine-tuning with frozen BN,
+    attribution): np_oracle's hand-derived form against autograd of oracle/torch_ref.py (stock torch ops)."""
+    import torch
+    import torch_ref as T
+    A, D, S, L, E, B = 24, 40, 5, 4, 8, 33
+    P, Bf = O.make_params(3, A, D, S, L, E)
+    rng = np.random.default_rng(0)
+    for k in Bf:                                           # non-trivial running statistics
+        if k.endswith("running_mean"):
+            Bf[k] = rng.standard_normal(Bf[k].shape).astype(np.float32) * 0.3
+        elif k.endswith("running_var"):
+            Bf[k] = rng.uniform(0.5, 2.0, Bf[k].shape).astype(np.float32)
+    a, b, site = O.make_batch(4, B, A, D, S)
+    _, eps = O.make_noise(5, B, L)
+    p, bufs = T.to_torch(P, Bf)
+    ta, tb, ts = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(site)
+    ra, rb, rc, mu, lv = T.forward(p, bufs, ta, tb, ts, False, None, torch.from_numpy(eps))
+    loss, *_ = T.loss_fn(ra, ta, rb, tb, rc, ts, mu, lv, 0.01, 0.5)
+    loss.backward()
+    P64, Bf64 = O.cast_tree(P, F64), O.cast_tree(Bf, F64)
+    oa, ob, oc, m, l, cache = O.vae_forward(P64, Bf64, a.astype(F64), b.astype(F64), site, None, eps.astype(F64), False)
+    tot, rec, cls, kld, g = O.vae_loss(oa, a.astype(F64), ob, b.astype(F64), oc, site, m, l, 0.01, 0.5)
+    np.testing.assert_allclose(tot, loss.item(), rtol=1e-5)
+    G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b"], g["recon_c"], g["mu"], g["logvar"])
+    for k, t_ in p.items():
+        np.testing.assert_allclose(G[k], t_.grad.numpy(), rtol=2e-3, atol=2e-4 + 3e-4 * np.abs(t_.grad.numpy()).max(), err_msg=k)

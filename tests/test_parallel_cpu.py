@@ -53,6 +53,17 @@ def _worker(rank, world, port, out):
         cover[lo:hi] = 1
         dist.all_reduce(cover)
         assert torch.all(cover == 1)
+        # equal=True: every rank the SAME number of rows (same number of training steps, or the all-reduce counts mismatch)
+        lo, hi = parallel.shard_rows(1001, rank, world, equal=True)
+        assert hi - lo == 1001 // world and lo == rank * (1001 // world)
+
+        # (2b) control-flow agreement: per-rank validation losses / BatchNorm running statistics become ONE value everywhere
+        v = parallel.all_ranks_mean(10.0 + rank, "cpu")
+        assert v == 10.0 + (world - 1) / 2
+        bn = torch.nn.Sequential(torch.nn.BatchNorm1d(4))
+        bn[0].running_mean.fill_(float(rank)); bn[0].running_var.fill_(1.0 + rank)
+        parallel.average_bn_buffers(bn)
+        assert torch.all(bn[0].running_mean == (world - 1) / 2) and torch.all(bn[0].running_var == 1.0 + (world - 1) / 2)
 
         # (3) DP semantics with the stock-torch restatement: each rank trains on its shard (per-shard BN),
         #     gradients are SUMMED through the hook; rank 0 compares with both shards computed locally.

@@ -55,11 +55,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mmvae_bn_finalize_args
 }
 
 __global__ void bn_eval_coeffs_kernel(int N, const float* gamma, const float* beta, const float* rm, const float* rv,
-                                      float eps, float* scale, float* shift) {
+                                      float eps, float* scale, float* shift, float* mean, float* rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < N) {
-        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        const float rs = 1.f / sqrtf(rv[c] + eps);
+        const float sc = gamma[c] * rs;
         scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+        if (mean) mean[c] = rm[c];          // backward through an eval-mode forward: xhat = (y - running_mean) * rstd
+        if (rstd) rstd[c] = rs;
     }
 }
 
@@ -70,8 +73,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mmvae_bn_bwd_final
         a.dbeta[col] += (float)sd;
         a.dgamma[col] += (float)sdx;
         a.coef[col] = a.gamma[col] * a.rstd[col];
-        a.coef[a.N + col] = (float)(sd / a.M);
-        a.coef[2 * a.N + col] = (float)(sdx / a.M);
+        // eval mode (running statistics): the normalisation constants do not depend on the batch, dy = gamma * rstd * d
+        a.coef[a.N + col] = a.eval_mode ? 0.f : (float)(sd / a.M);
+        a.coef[2 * a.N + col] = a.eval_mode ? 0.f : (float)(sdx / a.M);
     }
 }
 
@@ -192,7 +196,15 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(mmvae_fuse_fwd_args a) {
         float mu = 0.f, lv = 0.f;
         if (a.heads_a) { mu += a.heads_a[(long)b * a.ld_heads + l]; lv += a.heads_a[(long)b * a.ld_heads + a.L + l]; }
         if (a.heads_b) { mu += a.heads_b[(long)b * a.ld_heads + l]; lv += a.heads_b[(long)b * a.ld_heads + a.L + l]; }
-        if (a.table) { const long s = a.site[b]; mu += a.table[s * 2 * a.L + l]; lv += a.table[s * 2 * a.L + a.L + l]; }
+        if (a.table) {
+            // torch's Embedding device-asserts on an index outside [0, S); here the row is poisoned instead (NaN in mu / logvar /
+            // z and everything downstream) and no memory outside the table is touched
+            const long s = a.site[b];
+            const bool ok = s >= 0 && s < a.S;
+            const long sc = ok ? s : 0;
+            const float bad = ok ? 0.f : __builtin_nanf("");
+            mu += a.table[sc * 2 * a.L + l] + bad; lv += a.table[sc * 2 * a.L + a.L + l] + bad;
+        }
         if (a.n_mod > 1) { mu *= inv_n; lv *= inv_n; }
         a.mu[(long)b * a.L + l] = mu; a.logvar[(long)b * a.L + l] = lv;
         *zp = from_f32<ZT>(mu + a.eps[(long)b * a.L + l] * expf(0.5f * lv));
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
             gm[u] = a.g_mu ? a.g_mu[i] : 0.f; gl[u] = a.g_lv ? a.g_lv[i] : 0.f;
             ep[u] = a.eps[i]; lv[u] = a.logvar[i];
             sidx[u] = a.d_table ? a.site[b] : 0;
+            if (sidx[u] < 0 || sidx[u] >= a.S) sidx[u] = -1;                  // out of range: no scatter (the forward poisoned the row)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
             if (a.n_mod > 1) { dmu *= inv_n; dlv *= inv_n; }
             a.d_heads[(long)b * a.ld_heads + l] = dmu;
             a.d_heads[(long)b * a.ld_heads + a.L + l] = dlv;
-            if (a.d_table) {
+            if (a.d_table && sidx[u] >= 0) {
                 const long sx = sidx[u];
                 if (use_lds) { atomicAdd(&sT[sx * L2 + l], dmu); atomicAdd(&sT[sx * L2 + a.L + l], dlv); }
                 else { unsafeAtomicAdd(&a.d_table[sx * L2 + l], dmu); unsafeAtomicAdd(&a.d_table[sx * L2 + a.L + l], dlv); }
@@ -367,12 +380,14 @@ template <typename GT, int VA, int VD>
 __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
     const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float n_bad = 0.f;
     if (a.recon_a) s[0] = mse_part<GT, VA>(a, tid0, stride);
     if (a.recon_b) s[1] = bce_part<GT, VD>(a, tid0, stride);
     if (a.logits) {
         for (long r = tid0; r < a.B; r += stride) {
             const float* lg = a.logits + r * a.ld_logits;
-            const long y = a.site[r];
+            long y = a.site[r];
+            if (y < 0 || y >= a.S) { y = 0; n_bad += 1.f; }          // torch device-asserts; counted in sums[4] / out[4], see mmvae_hip.h
             float m = -INFINITY;
             for (int j = 0; j < a.S; ++j) m = fmaxf(m, lg[j]);
             float se = 0.f;
@@ -395,22 +410,45 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
             if (a.g_lv) a.g_lv[i] = -0.5f * a.beta * (1.f - ex);
         }
     }
-    __shared__ float red[4][4];
+    __shared__ float red[4][5];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const float v = wave_sum(s[k]); if (lane == 0) red[wid][k] = v; }
+    { const float v = wave_sum(n_bad); if (lane == 0) red[wid][4] = v; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 5) {
         const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
         if (v != 0.0) unsafeAtomicAdd(a.sums + threadIdx.x, v);
     }
+    if (a.out5 == nullptr) return;
+    // The block whose ticket is the last one turns the five sums into the tuple the reference returns (losses.py:44,46): no
+    // separate finalize launch.  Every block's sums are device-scope atomics that complete (vmcnt) before its fence and ticket;
+    // the last block reads them back with returning atomics (performed where the adds were performed, never a cached copy).
+    __shared__ unsigned last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] = atomicAdd(a.sums + k, 0.0);
+        const double recon = t[0] + t[1];
+        a.out5[0] = (float)(recon + (double)a.gamma * t[2] + (double)a.beta * t[3]);
+        a.out5[1] = (float)recon; a.out5[2] = (float)t[2]; a.out5[3] = (float)t[3]; a.out5[4] = (float)t[4];
+        *a.ticket = 0u;                                    // ready for the next launch (hipGraph replays re-run the memset anyway)
+    }
 }
 
-// out = {total, recon, class, kld} as the reference returns them (losses.py:44,46)
+// out = {total, recon, class, kld, labels out of range} as the reference returns them (losses.py:44,46); stand-alone form of the
+// tail of vae_loss_kernel (callers that keep `sums` to themselves)
 __global__ void loss_finalize_kernel(const double* sums, float beta, float gamma, float* out) {
     const double recon = sums[0] + sums[1];
     out[0] = (float)(recon + (double)gamma * sums[2] + (double)beta * sums[3]);
-    out[1] = (float)recon; out[2] = (float)sums[2]; out[3] = (float)sums[3];
+    out[1] = (float)recon; out[2] = (float)sums[2]; out[3] = (float)sums[3]; out[4] = (float)sums[4];
 }
 
 template <typename OT>
@@ -476,14 +514,24 @@ __device__ __forceinline__ void randn_quad(float* out, long n, long q, uint64_t 
 }
 
 // one launch for all dropout masks (one contiguous uint8 buffer) and eps of a forward pass
+// Last-block-done: every block draws a ticket AFTER it has read the device-resident counter; the block that draws the last
+// one advances the counter for the next launch and re-arms the ticket.  Replaces a 1-thread mmvae_counter_add launch per step.
+__device__ __forceinline__ void advance_counter_when_all_blocks_read(uint64_t* counter, uint64_t inc, unsigned* ticket, unsigned nblocks) {
+    __syncthreads();                                  // this block's threads hold the old value in registers
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (atomicAdd(ticket, 1u) == nblocks - 1) { *counter += inc; *ticket = 0u; }
+    }
+}
+
 __global__ __launch_bounds__(256) void noise_kernel(uint8_t* mask, long n_mask, float* eps, long n_eps, uint32_t thresh,
-                                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev) {
-    if (offset_dev) offset += *offset_dev;
+                                                    uint64_t seed, uint64_t offset, uint64_t* offset_dev, uint64_t advance, unsigned* ticket) {
+    if (offset_dev) offset += *(volatile uint64_t*)offset_dev;
     const long nqm = (n_mask + 15) / 16, nqe = (n_eps + 3) / 4;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nqm + nqe; q += (long)gridDim.x * blockDim.x) {
         if (q < nqm) mask_quad(mask, n_mask, q, thresh, seed, offset);
         else randn_quad(eps, n_eps, q - nqm, seed, offset + (uint64_t)nqm * 4);
     }
+    if (ticket) advance_counter_when_all_blocks_read(offset_dev, advance, ticket, gridDim.x);
 }
 
 __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
@@ -495,10 +543,10 @@ struct AdamWBatch { mmvae_adamw_item items[64]; };      // passed BY VALUE (2.5 
                                                         // so the launch is hipGraph-capturable even when gradients move
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, float lr, float b1, float b2,
                                                      float eps, float wd, float bc1, float rsqrt_bc2, int maximize,
-                                                     const uint64_t* step_dev) {
+                                                     uint64_t* step_dev, unsigned* ticket) {
     const mmvae_adamw_item it = batch.items[blockIdx.y];
     if (step_dev) {                                 // graph-capturable form: step count lives on the device
-        const float t = (float)(*step_dev + 1);
+        const float t = (float)(*(volatile uint64_t*)step_dev + 1);
         bc1 = 1.f - powf(b1, t);
         rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
     }
@@ -512,6 +560,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, floa
         p -= step * m / (sqrtf(v) * rsqrt_bc2 + eps);
         it.p[i] = p; it.m[i] = m; it.v[i] = v;
     }
+    if (ticket) advance_counter_when_all_blocks_read(step_dev, 1, ticket, gridDim.x * gridDim.y);
 }
 
 static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
@@ -525,7 +574,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 9; }
+extern "C" int mmvae_abi_version(void) { return 10; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -543,9 +592,9 @@ extern "C" int mmvae_bn_finalize(const mmvae_bn_finalize_args* a, void* stream) 
 }
 
 extern "C" int mmvae_bn_eval_coeffs(int32_t N, const float* gamma, const float* beta, const float* rm, const float* rv,
-                                    float eps, float* scale, float* shift, void* stream) {
+                                    float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     if (N <= 0 || !gamma || !beta || !rm || !rv || !scale || !shift) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, gamma, beta, rm, rv, eps, scale, shift);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, gamma, beta, rm, rv, eps, scale, shift, mean, rstd);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -647,6 +696,7 @@ extern "C" int mmvae_vae_loss(const mmvae_loss_args* a, void* stream) {
     if (a->recon_b && (!a->b || a->D <= 0)) return MMVAE_ERR_ARG;
     if (a->logits && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
     if (a->mu && (!a->logvar || a->L <= 0)) return MMVAE_ERR_ARG;
+    if ((a->out5 != nullptr) != (a->ticket != nullptr)) return MMVAE_ERR_ARG;
     if ((long)a->B * (a->A > a->D ? a->A : a->D) >= (1L << 32)) return MMVAE_ERR_ARG;
     const int gdt = a->g_a ? a->g_a_dtype : a->g_b_dtype;
     if (a->g_a && a->g_b && a->g_a_dtype != a->g_b_dtype) return MMVAE_ERR_DTYPE;
@@ -711,13 +761,14 @@ extern "C" int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const fl
 }
 
 extern "C" int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed,
-                           uint64_t offset, const uint64_t* offset_dev, void* stream) {
+                           uint64_t offset, uint64_t* offset_dev, uint32_t* advance_ticket, void* stream) {
     if ((n_mask > 0 && (!mask || ((uintptr_t)mask & 15))) || (n_eps > 0 && !eps) || n_mask < 0 || n_eps < 0 || n_mask + n_eps == 0 ||
-        keep_prob < 0.f || keep_prob > 1.f) return MMVAE_ERR_ARG;
+        keep_prob < 0.f || keep_prob > 1.f || (advance_ticket && !offset_dev)) return MMVAE_ERR_ARG;
+    const uint64_t advance = (uint64_t)((n_mask + 15) / 16 * 4 + (n_eps + 3) / 4);       // counter values this call consumes
     const double t = (double)keep_prob * 4294967296.0;
     const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     hipLaunchKernelGGL(noise_kernel, dim3(grid_for((n_mask + 15) / 16 + (n_eps + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       mask, n_mask, eps, n_eps, thresh, seed, offset, offset_dev);
+                       mask, n_mask, eps, n_eps, thresh, seed, offset, offset_dev, advance, advance_ticket);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -731,8 +782,9 @@ extern "C" int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stre
 
 extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                                const uint64_t* step_dev, void* stream) {
+                                uint64_t* step_dev, uint32_t* advance_ticket, void* stream) {
     if (!items_host || n_items <= 0 || (!step_dev && (bias_corr1 <= 0.f || bias_corr2 <= 0.f))) return MMVAE_ERR_ARG;
+    if (advance_ticket && (!step_dev || n_items > 64)) return MMVAE_ERR_ARG;       // one launch = one tick of the counter
     if (step_dev) { bias_corr1 = 1.f; bias_corr2 = 1.f; }
     for (int base = 0; base < n_items; base += 64) {
         AdamWBatch batch;
@@ -745,7 +797,7 @@ extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_it
         }
         const int gx = grid_for(max_numel, 256 * 4, 256);
         hipLaunchKernelGGL(adamw_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, batch, lr, beta1, beta2, eps,
-                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev);
+                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev, advance_ticket);
         MM_CHECK_LAUNCH();
     }
     return 0;

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -66,7 +66,7 @@ class BnFinalizeArgs(C.Structure):
 
 class BnBwdFinalizeArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("sum_d", vp), ("sum_dx", vp),
-                ("gamma", vp), ("rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp)]
+                ("gamma", vp), ("rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp), ("eval_mode", i32)]
 
 
 class FuseFwdArgs(C.Structure):
@@ -96,7 +96,7 @@ class LossArgs(C.Structure):
                 ("g_a", vp), ("g_a_dtype", i32), ("ld_ga", i64),
                 ("g_b", vp), ("g_b_dtype", i32), ("ld_gb", i64), ("grad_b_wrt_logit", i32),
                 ("g_c", vp), ("ld_gc", i64),
-                ("g_mu", vp), ("g_lv", vp)]
+                ("g_mu", vp), ("g_lv", vp), ("out5", vp), ("ticket", vp)]
 
 
 class AdamWItem(C.Structure):
@@ -110,7 +110,7 @@ _SIGNATURES = {
     "mmvae_gemm_nt": [C.POINTER(GemmNtArgs), vp],
     "mmvae_gemm_tn": [C.POINTER(GemmTnArgs), vp],
     "mmvae_bn_finalize": [C.POINTER(BnFinalizeArgs), vp],
-    "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp],
+    "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],
     "mmvae_bn_bwd_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp],
     "mmvae_embed_table_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -122,9 +122,9 @@ _SIGNATURES = {
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
     "mmvae_scale_many": [C.POINTER(ScaleItem), i32, vp, vp],
-    "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, vp],
+    "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, vp, vp],
     "mmvae_counter_add": [vp, C.c_uint64, vp],
-    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp],
+    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
 }
 EXPORTED = ["mmvae_abi_version"] + sorted(_SIGNATURES)
 

@@ -61,8 +61,18 @@ class NoiseSource:
     def offset_tensor(self, device):
         t = self._offsets.get(device)
         if t is None:
-            t = self._offsets[device] = torch.zeros(1, dtype=torch.int64, device=device)
+            t = self._offsets[device] = torch.zeros(2, dtype=torch.int64, device=device)     # [Philox offset, ticket of the advancing launch]
         return t
+
+    def state_dict(self, device):
+        """Position of the Philox stream on `device` (one host read): part of a resumable checkpoint."""
+        t = self._offsets.get(torch.device(device) if not isinstance(device, torch.device) else device)
+        return {"offset": 0 if t is None else int(t[0].item())}
+
+    def load_state_dict(self, state, device):
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        t = self.offset_tensor(device)
+        t.copy_(torch.tensor([int(state["offset"]), 0], dtype=torch.int64))
 
     def draw(self, B, widths, Ld, device):
         """-> ([uint8 (B,w) keep-mask for w in widths], eps fp32 (B,Ld) or None if Ld is None)."""
@@ -87,8 +97,7 @@ class NoiseSource:
         buf = torch.empty(total, dtype=torch.uint8, device=device) if total else None
         eps = torch.empty(B, Ld, dtype=torch.float32, device=device) if Ld is not None else None
         off = self.offset_tensor(device)
-        used = ops.noise(buf, eps, 1.0 - DROP_P, self._seed(), 0, off)
-        ops.counter_add(off, used)
+        ops.noise(buf, eps, 1.0 - DROP_P, self._seed(), 0, off, advance=True)        # the launch advances the device offset itself
         return [buf[o:o + B * w].view(B, w) for o, w in zip(segs, widths)], eps
 
 
@@ -207,7 +216,7 @@ class EncoderMLP:
                 new_pro = (st.scale, st.shift, mask, 1.0 / (1.0 - DROP_P))
             else:
                 ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, tag=f"{self.name}.L{len(saved)}.fwd")
-                ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, st.scale, st.shift, bn.eps)
+                ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, st.scale, st.shift, bn.eps, st.mean, st.rstd)
                 new_pro = (st.scale, st.shift, None, 1.0)
             saved.append((h, pro, y, st, new_pro))
             h, pro = y, new_pro
@@ -217,8 +226,10 @@ class EncoderMLP:
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
-    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None):
-        """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated)."""
+    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None, train=True):
+        """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated).
+        train=False: the forward ran in eval mode (running statistics, no dropout) -- torch's
+        batch_norm(training=False) backward: dy = gamma * rstd * d, no batch-statistics correction."""
         B, dev = d_heads.shape[0], d_heads.device
         adt = act_dtype(prec)
         nt = (B + TILE - 1) // TILE
@@ -243,11 +254,11 @@ class EncoderMLP:
             d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
             if _BN_BWD_RECOMPUTE:
                 ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
-                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
                 ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
             else:
                 ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
-                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef)
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
                 if i == 0 and _FUSE_BN_APPLY:
                     # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
                     tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
@@ -545,9 +556,9 @@ class VAEGraph:
         d_table = extra[-1][:n_tab].view(-1, 2 * Ld) if site is not None else None
         ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, saved["eps"], saved["logvar"], d_heads, d_table, site)
         if "enc_a" in saved:
-            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)])
+            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)], train=saved["train"])
         if "enc_b" in saved:
-            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):])
+            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):], train=saved["train"])
         if site is not None:
             self.enc_c.backward(d_table, grads)
         if side is not None:

@@ -156,6 +156,11 @@ class _LossGeneralFn(torch.autograd.Function):
         return (None, *out)
 
 
+def engine_noise():
+    from . import engine
+    return engine.GLOBAL_NOISE
+
+
 def _tag_of(t):
     return getattr(t, "_mmvae", None) if t is not None else None
 
@@ -169,11 +174,33 @@ def fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         return _fused_loss(terms, beta, gamma, class_weights, unit_grad)
 
 
+def _validate_loss_args(dev, B, ra, a, rb, b, lg, site, mu, lv, class_weights):
+    """The kernel takes raw pointers: everything torch's own losses would reject (F.mse_loss / binary_cross_entropy /
+    cross_entropy on mismatched devices or shapes, losses.py:31,34,39) is rejected here, before any launch."""
+    for nm, pred, tgt in (("a", ra, a), ("b", rb, b), ("logvar", mu, lv)):
+        if pred is None:
+            continue
+        if tgt.device != pred.device or pred.device != dev:
+            raise RuntimeError(f"vae_loss: '{nm}' tensors are on different devices ({pred.device} vs {tgt.device}); "
+                               "the MI355X loss kernel needs all of them on one CUDA/HIP device")
+        if pred.dim() != 2 or tuple(tgt.shape) != tuple(pred.shape) or pred.shape[0] != B:
+            raise RuntimeError(f"vae_loss: shape mismatch for '{nm}': prediction {tuple(pred.shape)} vs target {tuple(tgt.shape)} (batch {B})")
+    if lg is not None:
+        if site.device != dev or lg.device != dev:
+            raise RuntimeError(f"vae_loss: site labels / logits are on another device ({site.device}, {lg.device}) than {dev}")
+        if lg.dim() != 2 or lg.shape[0] != B or site.dim() != 1 or site.shape[0] != B:
+            raise RuntimeError(f"vae_loss: site must have shape ({B},) for logits {tuple(lg.shape)}, got {tuple(site.shape)}")
+        if site.dtype in (torch.float16, torch.float32, torch.float64, torch.bfloat16, torch.bool):
+            raise RuntimeError(f"vae_loss: site labels must be integer class indices, got {site.dtype}")
+        if class_weights is not None and class_weights.numel() != lg.shape[1]:
+            raise RuntimeError(f"vae_loss: class_weights has {class_weights.numel()} entries for {lg.shape[1]} classes")
+
+
 def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     """terms: dict with optional entries
          'a': (recon_a, a)  sum-MSE           'b': (recon_b, b)  sum-BCE (clamped logs)
          'c': (logits, site) weighted sum-CE  'kl': (mu, logvar)
-    Returns (total (0-dim tensor, differentiable), out4 (device fp32 [total, recon, class, kld]))."""
+    Returns (total (0-dim tensor, differentiable), out5 (device fp32 [total, recon, class, kld, labels out of range]))."""
     any_t = next(v[0] for v in terms.values() if v is not None)
     dev, B = any_t.device, any_t.shape[0]
     if not any_t.is_cuda:
@@ -182,8 +209,11 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     rb, b = terms.get("b") or (None, None)
     lg, site = terms.get("c") or (None, None)
     mu, lv = terms.get("kl") or (None, None)
+    _validate_loss_args(dev, B, ra, a, rb, b, lg, site, mu, lv, class_weights)
     if site is not None and site.dtype != torch.int64:
         site = site.long()
+    if site is not None:
+        site = site.contiguous()
     cw = None if class_weights is None else class_weights.to(device=dev, dtype=torch.float32).contiguous()
     need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (ra, rb, lg, mu, lv))
 
@@ -192,8 +222,7 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     ra_, a_, rb_, b_, lg_, mu_, lv_ = (prep(ra), prep(a), prep(rb), prep(b), prep(lg), prep(mu), prep(lv))
     if mu_ is not None:
         mu_, lv_ = mu_.contiguous(), lv_.contiguous()
-    sums = torch.zeros(4, dtype=torch.float64, device=dev)
-    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    sums, ticket, out4 = ops.loss_workspace(dev)          # out4: [total, recon, class, kld, labels out of range]
 
     # ---- fused hand-off: all differentiable inputs are outputs of ONE forward of our model --------------------
     tags = [_tag_of(t) for t in (ra, rb, lg, mu, lv) if t is not None and t.requires_grad]
@@ -216,8 +245,8 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         g_mu = torch.empty(B, mu.shape[1], dtype=torch.float32, device=dev) if mu is not None else None
         g_lv = torch.empty_like(g_mu) if mu is not None else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv)
-        ops.loss_finalize(sums, beta, gamma, out4)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv,
+                     out5=out4, ticket=ticket)
         stash = {"g_outs": g_outs, "g_mu": g_mu, "g_lv": g_lv, "scale": None, "unit_grad": bool(unit_grad)}
         if g_mu is None:                       # KL term absent: nothing flows into mu/logvar from this loss
             stash["g_mu"] = torch.zeros(B, saved["logvar"].shape[1], dtype=torch.float32, device=dev)
@@ -236,8 +265,8 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         gm = torch.empty_like(mu_) if (need_grad and mu is not None and mu.requires_grad) else None
         gl = torch.empty_like(lv_) if (need_grad and lv is not None and lv.requires_grad) else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl)
-        ops.loss_finalize(sums, beta, gamma, out4)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl,
+                     out5=out4, ticket=ticket)
         grads = []
         for t, g in ((ra, ga), (rb, gb), (lg, gc), (mu, gm), (lv, gl)):
             if t is not None:
@@ -247,6 +276,15 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     inputs = [t for t in (ra, rb, lg, mu, lv) if t is not None]
     total = _LossGeneralFn.apply(spec, *inputs)
     return total, out4
+
+
+def read_losses(out5):
+    """The ONE host read of the loss (the reference's three `.item()` calls, losses.py:46): [total, recon, class, kld] as
+    floats.  Raises if the kernel met a class index outside [0, n_sites) (torch's cross_entropy device-asserts there)."""
+    vals = out5.tolist()
+    if vals[4] != 0.0:
+        raise RuntimeError(f"vae_loss: {int(vals[4])} class index(es) in `site` outside [0, n_classes)")
+    return vals[:4]
 
 
 # --------------------------------------------------------------------------------------------
@@ -287,7 +325,7 @@ class EncoderMLPFn(torch.autograd.Function):
         rt.ensure(prec, x.device)
         masks = noise.draw(x.shape[0], rt.block.widths(), None, x.device)[0] if train else None
         heads, saved = rt.block.forward(prec, x, train, masks)
-        ctx.rt, ctx.prec, ctx.saved = rt, prec, saved
+        ctx.rt, ctx.prec, ctx.saved, ctx.train = rt, prec, saved, train
         Ld = rt.block.latent
         return heads[:, :Ld], heads[:, Ld:]
 
@@ -303,7 +341,7 @@ class EncoderMLPFn(torch.autograd.Function):
         if g_lv is not None:
             d_heads[:, Ld:].copy_(g_lv)
         grads = _alloc_block_grads(blk, y.device)
-        blk.backward(ctx.prec, ctx.saved, d_heads, grads)
+        blk.backward(ctx.prec, ctx.saved, d_heads, grads, train=ctx.train)
         out = [grads[p] for p in blk.params()]
         del grads
         return (None, None, None, None, None, *out)

@@ -19,7 +19,8 @@ from . import functional as F_
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, a, b, site, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None):
+    def __init__(self, model, optimizer, a, b, site, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None,
+                 preserve_state=False):
         if not a.is_cuda:
             raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors; there is no CPU fallback")
         self.model, self.optimizer = model, optimizer
@@ -27,6 +28,11 @@ class GraphedTrainStep:
         self.beta, self.gamma, self.class_weights = float(beta), float(gamma), class_weights
         self.warmup = warmup
         self.reduce = reduce                                    # callable(flat_grad_arena) or None
+        # preserve_state: the eager warm-up steps (they build weight / optimiser tables and allocator pools, and capture
+        # cannot run without them) are UNDONE before the capture -- parameters, BatchNorm buffers, Adam moments and step
+        # counts, Philox offset -- so that constructing / re-capturing the step does not advance training (resume from a
+        # checkpoint, re-capture after an LR change).  Default False: warm-up steps are ordinary training steps.
+        self.preserve_state = preserve_state
         self.graph = self.graph_opt = None
         self._one = torch.ones((), dtype=torch.float32, device=a.device)
         self.recapture()
@@ -64,6 +70,13 @@ class GraphedTrainStep:
         g = self.model._graph()
         sync, g.grad_sync = g.grad_sync, (None if self.reduce is not None else g.grad_sync)   # two-graph form: the reduce runs between the replays
         try:
+            snap = None
+            if self.preserve_state:
+                if self.warmup < 1:
+                    raise ValueError("preserve_state needs at least one (undone) warm-up step")
+                dev = self.a.device
+                snap = ({k: v.clone() for k, v in self.model.state_dict().items()}, self.optimizer.snapshot(),
+                        F_.engine_noise().state_dict(dev))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                        # eager warm-up: builds weight / optimiser tables, allocator pools
@@ -76,6 +89,14 @@ class GraphedTrainStep:
                         self.optimizer.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if snap is not None:                                 # in place: every address the capture will record stays valid
+                with torch.no_grad():
+                    cur = self.model.state_dict()
+                    for k, v in snap[0].items():
+                        cur[k].copy_(v)
+                self.optimizer.restore(snap[1])
+                F_.engine_noise().load_state_dict(snap[2], self.a.device)
+                torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             if self.reduce is None:
                 with torch.cuda.graph(self.graph):
@@ -93,7 +114,7 @@ class GraphedTrainStep:
         return self
 
     def __call__(self):
-        """Run one training step; returns the device tensor [total, recon, class, kld] (fp32) of that step."""
+        """Run one training step; returns the device tensor [total, recon, class, kld, labels out of range] (fp32) of that step."""
         self.graph.replay()
         if self.reduce is not None:
             self.reduce(self.flat)
@@ -103,7 +124,7 @@ class GraphedTrainStep:
 
     def losses(self):
         """(total, recon, class, kld) as floats: the ONE host read of the step (vae_loss does the same)."""
-        return tuple(self.out4.tolist())
+        return tuple(F_.read_losses(self.out4))
 
     # --- pipelined logging -------------------------------------------------------------------------------------------
     # `losses()` right after a replay makes the host wait for the step, and the GPU then waits for the host to wake up,
@@ -114,7 +135,7 @@ class GraphedTrainStep:
     def step_logged(self):
         """Launch one step; returns the (total, recon, class, kld) floats of the PREVIOUS step (None on the first call)."""
         if getattr(self, "_pin", None) is None:
-            self._pin = [torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pin = [torch.empty(5, dtype=torch.float32).pin_memory() for _ in range(2)]
             self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._pin_n = 0                                      # steps launched through this method
         self()
@@ -125,7 +146,7 @@ class GraphedTrainStep:
         if self._pin_n < 2:
             return None
         self._pin_ev[k ^ 1].synchronize()
-        return tuple(self._pin[k ^ 1].tolist())
+        return tuple(F_.read_losses(self._pin[k ^ 1]))
 
     def flush_logged(self):
         """Losses of the last step launched by `step_logged()` (waits for it)."""
@@ -133,4 +154,4 @@ class GraphedTrainStep:
             return None
         k = (self._pin_n - 1) & 1
         self._pin_ev[k].synchronize()
-        return tuple(self._pin[k].tolist())
+        return tuple(F_.read_losses(self._pin[k]))

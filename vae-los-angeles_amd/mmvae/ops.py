@@ -45,6 +45,24 @@ class KernelProbe:
 PROBE = None
 
 
+class probe_span:
+    """`with probe_span(tag, bytes)`: brackets a non-GEMM launch with events when a KernelProbe is installed (bench.py's
+    survey of the step); `nbytes` = algorithmic HBM bytes of the launch (operands read once + results written once)."""
+
+    def __init__(self, tag, nbytes):
+        self.tag, self.nbytes, self.t0 = tag, nbytes, None
+
+    def __enter__(self):
+        if PROBE is not None and PROBE.wants(self.tag):
+            self.t0 = PROBE.begin()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t0 is not None:
+            PROBE.end(self.tag, self.t0, dict(kind="stream", bytes=int(self.nbytes() if callable(self.nbytes) else self.nbytes)))
+        return False
+
+
 def ceil_to(x, m):
     return (x + m - 1) // m * m
 
@@ -168,7 +186,8 @@ class WeightPrep:
         return self._keys != self._current_keys()
 
     def run(self):
-        L.check(L.load().mmvae_prep_weights(self.table.data_ptr(), self.n, _stream()), "mmvae_prep_weights")
+        with probe_span("prep_weights", lambda: sum(6 * w.numel() for pl in self.linears for w in pl.srcs)):
+            L.check(L.load().mmvae_prep_weights(self.table.data_ptr(), self.n, _stream()), "mmvae_prep_weights")
 
 
 # --------------------------------------------------------------------------------------------
@@ -263,21 +282,22 @@ def bn_finalize(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, 
     L.check(L.load().mmvae_bn_finalize(C.byref(a), _stream()), "mmvae_bn_finalize")
 
 
-def bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift, eps=BN_EPS):
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift, eps=BN_EPS, mean=None, rstd=None):
     L.check(L.load().mmvae_bn_eval_coeffs(gamma.numel(), gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
-                                          running_var.data_ptr(), eps, scale.data_ptr(), shift.data_ptr(), _stream()),
+                                          running_var.data_ptr(), eps, scale.data_ptr(), shift.data_ptr(), _p(mean), _p(rstd), _stream()),
             "mmvae_bn_eval_coeffs")
 
 
-def bn_bwd_finalize(M, N, stats, gamma, rstd, dgamma, dbeta, coef):
+def bn_bwd_finalize(M, N, stats, gamma, rstd, dgamma, dbeta, coef, eval_mode=False):
     a = L.BnBwdFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
-                            gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr())
+                            gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), int(eval_mode))
     L.check(L.load().mmvae_bn_bwd_finalize(C.byref(a), _stream()), "mmvae_bn_bwd_finalize")
 
 
 def bn_bwd_apply(d, y, N, mean, rstd, coef):
-    L.check(L.load().mmvae_bn_bwd_apply(_dt(d), d.shape[0], N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y),
-                                        mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), _stream()), "mmvae_bn_bwd_apply")
+    with probe_span(f"bn_bwd_apply.N{N}", 3 * d.shape[0] * N * d.element_size()):
+        L.check(L.load().mmvae_bn_bwd_apply(_dt(d), d.shape[0], N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y),
+                                            mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), _stream()), "mmvae_bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------
@@ -302,7 +322,8 @@ def fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z):
     a = L.FuseFwdArgs(B, Ld, n_mod, _p(heads_a), _p(heads_b), _ld(hd) if hd is not None else 0,
                       _p(table), _p(site), table.shape[0] if table is not None else 0,
                       eps.data_ptr(), mu.data_ptr(), logvar.data_ptr(), z.data_ptr(), _dt(z), _ld(z))
-    L.check(L.load().mmvae_fuse_reparam_fwd(C.byref(a), _stream()), "mmvae_fuse_reparam_fwd")
+    with probe_span("fuse_reparam_fwd", B * (8 * Ld * (n_mod - (table is not None)) + 8 * (table is not None) + 12 * Ld + z.element_size() * _ld(z))):
+        L.check(L.load().mmvae_fuse_reparam_fwd(C.byref(a), _stream()), "mmvae_fuse_reparam_fwd")
 
 
 def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_table, site):
@@ -310,12 +331,22 @@ def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_tabl
     dzs = list(dzs) + [None] * (3 - len(dzs))
     a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dzs[0].data_ptr(), _p(dzs[1]), _p(dzs[2]), _ld(dzs[0]), eps.data_ptr(), logvar.data_ptr(),
                       d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[0] if d_table is not None else 0)
-    L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
+    n_dz = sum(1 for d in dzs if d is not None)
+    with probe_span("fuse_reparam_bwd", B * Ld * 4 * (n_dz + (g_mu is not None) + (g_lv is not None) + 2 + 2)):
+        L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
+
+
+def loss_workspace(device):
+    """-> (sums float64[5], ticket, out5 float32[5]) from ONE zero-filled allocation (one memset): the accumulators of
+    mmvae_vae_loss, the ticket of its in-kernel finalisation and the tuple it leaves behind."""
+    buf = torch.zeros(5 * 8 + 8 + 5 * 4 + 4, dtype=torch.uint8, device=device)
+    return buf[:40].view(torch.float64), buf[40:48].view(torch.int32), buf[48:68].view(torch.float32)
 
 
 def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site=None, class_weights=None,
              mu=None, logvar=None, beta=1e-3, gamma=1.0, sums=None, g_a=None, g_b=None, grad_b_wrt_logit=False,
-             g_c=None, g_mu=None, g_lv=None):
+             g_c=None, g_mu=None, g_lv=None, out5=None, ticket=None):
+    """sums: zeroed float64[5].  out5 + ticket (loss_workspace): the launch also writes the finalised tuple."""
     x = L.LossArgs()
     x.B = B
     if recon_a is not None:
@@ -334,11 +365,24 @@ def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site
     if g_c is not None:
         x.g_c, x.ld_gc = g_c.data_ptr(), _ld(g_c)
     x.g_mu, x.g_lv = _p(g_mu), _p(g_lv)
-    L.check(L.load().mmvae_vae_loss(C.byref(x), _stream()), "mmvae_vae_loss")
+    assert sums.dtype == torch.float64 and sums.numel() >= 5
+    x.out5, x.ticket = _p(out5), _p(ticket)
+
+    def nbytes():
+        n = 0
+        for pred, g in ((recon_a, g_a), (recon_b, g_b), (logits, g_c)):
+            if pred is not None:
+                n += 2 * B * pred.shape[1] * 4 + (0 if g is None else B * pred.shape[1] * g.element_size())
+        if mu is not None:
+            n += B * mu.shape[1] * 4 * (2 + (g_mu is not None) + (g_lv is not None))
+        return n
+    with probe_span("vae_loss", nbytes):
+        L.check(L.load().mmvae_vae_loss(C.byref(x), _stream()), "mmvae_vae_loss")
 
 
-def loss_finalize(sums, beta, gamma, out4):
-    L.check(L.load().mmvae_loss_finalize(sums.data_ptr(), beta, gamma, out4.data_ptr(), _stream()), "mmvae_loss_finalize")
+def loss_finalize(sums, beta, gamma, out5):
+    assert out5.numel() >= 5
+    L.check(L.load().mmvae_loss_finalize(sums.data_ptr(), beta, gamma, out5.data_ptr(), _stream()), "mmvae_loss_finalize")
 
 
 def sigmoid_bwd(g, p, out):
@@ -359,12 +403,18 @@ def scale_if_needed(x, scale):
     L.check(L.load().mmvae_scale_if_needed(x.data_ptr(), _dt(x), x.numel(), scale.data_ptr(), _stream()), "mmvae_scale_if_needed")
 
 
-def noise(mask, eps, keep_prob, seed, offset, offset_dev=None):
+def noise(mask, eps, keep_prob, seed, offset, offset_dev=None, advance=False):
     """Fill `mask` (uint8, any shape, contiguous; may be None) and `eps` (fp32; may be None) from the Philox stream
-    (seed, offset [+ *offset_dev]).  Returns the number of counter values consumed."""
+    (seed, offset [+ *offset_dev]).  Returns the number of counter values consumed.  advance=True: offset_dev is an
+    int64[2] tensor (counter, zeroed ticket) and the launch itself moves the counter past what it consumed."""
     n_mask = 0 if mask is None else mask.numel()
     n_eps = 0 if eps is None else eps.numel()
-    L.check(L.load().mmvae_noise(_p(mask), n_mask, keep_prob, _p(eps), n_eps, seed, offset, _p(offset_dev), _stream()), "mmvae_noise")
+    ticket = None
+    if advance:
+        assert offset_dev is not None and offset_dev.numel() >= 2
+        ticket = offset_dev.data_ptr() + 8
+    with probe_span("noise", n_mask + 4 * n_eps):
+        L.check(L.load().mmvae_noise(_p(mask), n_mask, keep_prob, _p(eps), n_eps, seed, offset, _p(offset_dev), ticket, _stream()), "mmvae_noise")
     return (n_mask + 15) // 16 * 4 + (n_eps + 3) // 4
 
 
@@ -381,6 +431,12 @@ def counter_add(counter, inc):
 
 
 def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=None):
-    """items: ctypes array of AdamWItem in host memory (device pointers inside)."""
-    L.check(L.load().mmvae_adamw_step(C.cast(items, C.c_void_p), len(items), lr, b1, b2, eps, wd, bc1, bc2, int(maximize),
-                                      _p(step_dev), _stream()), "mmvae_adamw_step")
+    """items: ctypes array of AdamWItem in host memory (device pointers inside).  step_dev: int64[2] tensor (step count,
+    zeroed ticket): bias corrections from the device counter, which the launch itself increments (<= 64 tensors; beyond
+    that one mmvae_counter_add follows the launches)."""
+    tick = step_dev is not None and len(items) <= 64
+    with probe_span("adamw", lambda: 28 * sum(it.n for it in items)):
+        L.check(L.load().mmvae_adamw_step(C.cast(items, C.c_void_p), len(items), lr, b1, b2, eps, wd, bc1, bc2, int(maximize),
+                                          _p(step_dev), (step_dev.data_ptr() + 8) if tick else None, _stream()), "mmvae_adamw_step")
+    if step_dev is not None and not tick:
+        counter_add(step_dev, 1)

@@ -3,14 +3,17 @@ optimize_hyperparameters.py:93-97, train_dna2rna.py:185-189) with every paramete
 by ONE HIP launch (mmvae_adamw_step); the (p, g, m, v) pointer records travel in the kernel arguments.
 
 State layout and hyper-parameter names follow torch.optim.AdamW (`exp_avg`, `exp_avg_sq`,
-`step`; `lr`, `betas`, `eps`, `weight_decay`, `maximize`) so `state_dict()` round-trips and LR
-schedulers such as ReduceLROnPlateau (train_dna2rna.py:190-195) work unchanged.
+`step`; `lr`, `betas`, `eps`, `weight_decay`, `maximize`) so `state_dict()` / `load_state_dict()`
+round-trip (also with a stock torch.optim.AdamW) and LR schedulers such as ReduceLROnPlateau
+(train_dna2rna.py:190-195) work unchanged.
 
-The step count used for the bias corrections lives ON THE DEVICE (one uint64 per step bucket,
-advanced by mmvae_counter_add after the launch), so `step()` is hipGraph-capturable: a replayed
-graph keeps counting.  `lr` is passed by value: re-capture when a scheduler changes it."""
-import ctypes as C
+The step count used for the bias corrections lives ON THE DEVICE (one int64 per step bucket, incremented
+by the AdamW launch itself once all its blocks have read it), so `step()` is hipGraph-capturable: a
+replayed graph keeps counting.  `lr` is passed by value: re-capture when a scheduler changes it.
 
+Caches (pointer tables, the steady-state fast path, device counters) are keyed on the identity of
+everything the kernel dereferences -- parameter, gradient and moment addresses and the set of parameters
+that have a gradient -- and are dropped by `load_state_dict()` / `add_param_group()`."""
 import torch
 
 from . import _lib as L
@@ -22,54 +25,88 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
-        self._tables = {}
-        self._step_dev = {}           # (group, host step at creation) -> int64[1] device counter
-        self._fast = {}               # group -> [params, grad ptrs, records, pending host steps, device counter]
+        self._drop_caches()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # caches
+    # ------------------------------------------------------------------------------------------------------------
+    def _drop_caches(self):
+        self._tables = {}             # key id -> (pointer key, ctypes records)
+        self._step_dev = {}           # (group / bucket, device) -> [host mirror of the count, int64[2] device (count, ticket)]
+        self._fast = {}               # group index -> dict(params, key, items, pending, step_dev)
+
+    @staticmethod
+    def _ptr_key(entries):
+        return tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()) for p, s in entries)
 
     def _table(self, key_id, entries):
         """Host-side array of (p, g, m, v, n) records; the launch copies it into its kernel arguments."""
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()) for p, s in entries)
+        key = self._ptr_key(entries)
         cached = self._tables.get(key_id)
         if cached is not None and cached[0] == key:
-            return cached[1]
+            return cached[1], key
         items = (L.AdamWItem * len(entries))(*[L.AdamWItem(p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(),
                                                             s["exp_avg_sq"].data_ptr(), p.numel()) for p, s in entries])
         self._tables[key_id] = (key, items)
-        return items
+        return items, key
 
-    def _device_step(self, gi, bucket_step, device):
-        """Device counter holding (steps already applied) for the parameters of this bucket."""
-        k = (gi, str(device))
+    def _device_step(self, key, bucket_step, device):
+        """Device counter holding (steps already applied) for the parameters of this bucket: int64[2] = (count, ticket)."""
+        k = (key, str(device))
         ent = self._step_dev.get(k)
         if ent is None or ent[0] != bucket_step - 1:
-            t = torch.full((1,), bucket_step - 1, dtype=torch.int64, device=device)
+            t = torch.tensor([bucket_step - 1, 0], dtype=torch.int64, device=device)
             ent = [bucket_step - 1, t]
             self._step_dev[k] = ent
         ent[0] = bucket_step
         return ent[1]
 
+    def _fast_valid(self, group, fast):
+        """The cached launch is still THE launch: same parameters have gradients, and parameters, gradients and moments
+        still live where the cached records point (a parameter that gained a gradient, a re-allocated gradient arena or
+        reloaded moments all fail this and take the general path, which rebuilds everything)."""
+        ps = fast["params"]
+        n = 0
+        for p in group["params"]:
+            if p.grad is not None:
+                n += 1
+        if n != len(ps):
+            return False
+        state = self.state
+        for p, (pp, gp, mp, vp) in zip(ps, fast["key"]):
+            g = p.grad
+            if g is None or g.data_ptr() != gp or p.data_ptr() != pp:
+                return False
+            st = state.get(p)
+            if not st or st["exp_avg"].data_ptr() != mp or st["exp_avg_sq"].data_ptr() != vp:
+                return False
+        return True
+
+    # ------------------------------------------------------------------------------------------------------------
+    # hipGraph bookkeeping
+    # ------------------------------------------------------------------------------------------------------------
     def note_replayed_step(self):
         """Bookkeeping after a hipGraph replay that contained step(): the device counters advanced, mirror it on the host."""
-        self._sync_fast_steps()
-        for group in self.param_groups:
-            for p in group["params"]:
-                st = self.state.get(p)
-                if st:
-                    st["step"] += 1
-        for ent in self._step_dev.values():
-            ent[0] += 1
+        self._bump_host_steps(+1)
 
     def note_captured_step(self):
         """A step() that ran under hipGraph CAPTURE only recorded launches: take its host-side counting back."""
-        self._sync_fast_steps()
+        self._bump_host_steps(-1)
+
+    def _bump_host_steps(self, inc):
+        seen = set()
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state.get(p)
-                if st:
-                    st["step"] -= 1
+                if st and id(st["step"]) not in seen:             # aliased counters (fast path) move once
+                    seen.add(id(st["step"]))
+                    st["step"] += inc
         for ent in self._step_dev.values():
-            ent[0] -= 1
+            ent[0] += inc
 
+    # ------------------------------------------------------------------------------------------------------------
+    # step
+    # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -77,22 +114,21 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            buckets = {}            # step number -> [(param, state)]; normally a single bucket
+            b1, b2 = group["betas"]
             fast = self._fast.get(gi)
-            if fast is not None and all(p.grad is not None and p.grad.data_ptr() == g for p, g in zip(fast[0], fast[1])):
-                # steady state: same parameters, gradients at the same addresses as last step -> reuse records,
-                # one shared host step counter (the per-parameter `step` tensors are refreshed in state_dict())
-                fast[3] += 1
-                b1, b2 = group["betas"]
+            if fast is not None and self._fast_valid(group, fast):
+                # steady state: the parameters of the bucket share ONE host `step` tensor (aliased in their state entries),
+                # so `optimizer.state[p]["step"]` stays current at the price of a single host increment
+                fast["step_t"] += 1
                 with ops.pinned_stream():
-                    ops.adamw_step(fast[2], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
-                                   group["maximize"], step_dev=fast[4])
-                    ops.counter_add(fast[4], 1)
+                    ops.adamw_step(fast["items"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
+                                   group["maximize"], step_dev=fast["step_dev"])
                 for ent in self._step_dev.values():
-                    if ent[1] is fast[4]:
+                    if ent[1] is fast["step_dev"]:
                         ent[0] += 1
                 continue
             self._sync_fast_steps(gi)
+            buckets = {}            # step number -> [(param, state)]; normally a single bucket
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -107,33 +143,93 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                else:
+                    self._adopt_loaded_state(p, st)
                 st["step"] += 1
                 buckets.setdefault(int(st["step"].item()), []).append((p, st))
-            b1, b2 = group["betas"]
             for step_no, entries in buckets.items():
                 single = len(buckets) == 1
-                items = self._table((gi, 0 if single else step_no), entries)
+                items, key = self._table((gi, 0 if single else step_no), entries)
                 step_dev = self._device_step(gi if single else (gi, step_no), step_no, entries[0][0].device)
-                ops.adamw_step(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
-                               group["maximize"], step_dev=step_dev)
-                ops.counter_add(step_dev, 1)
+                with ops.pinned_stream():
+                    ops.adamw_step(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
+                                   group["maximize"], step_dev=step_dev)
                 if single:
-                    ps = [p for p, _ in entries]
-                    self._fast[gi] = [ps, [p.grad.data_ptr() for p in ps], items, 0, step_dev]
+                    shared = entries[0][1]["step"]
+                    for _, st in entries:
+                        st["step"] = shared                       # un-aliased again by _sync_fast_steps()
+                    self._fast[gi] = dict(params=[p for p, _ in entries], key=key, items=items, step_t=shared, step_dev=step_dev)
         return loss
 
+    @staticmethod
+    def _adopt_loaded_state(p, st):
+        """State that came in through load_state_dict(): torch casts it to the parameter's dtype / device already; make
+        sure of the layout the kernel assumes (dense fp32 next to the parameter, `step` a host scalar tensor)."""
+        for k in ("exp_avg", "exp_avg_sq"):
+            t = st[k]
+            if t.device != p.device or t.dtype != torch.float32 or not t.is_contiguous():
+                st[k] = t.to(device=p.device, dtype=torch.float32).contiguous()
+        # a tensor of its own per parameter: torch.load() keeps the `step` tensors of a checkpoint ALIASED when they were
+        # aliased at save time (our fast path shares one counter) and Optimizer.load_state_dict passes `step` through as it
+        # is -- the per-parameter `+= 1` below would then count one shared tensor once per parameter
+        st["step"] = torch.tensor(float(st["step"]))
+
     def _sync_fast_steps(self, gi=None):
-        """Fold the steps taken on the fast path back into the per-parameter `step` tensors."""
+        """Leave the fast path of group gi (all groups when None): every parameter gets a `step` tensor of its own again
+        (they were aliased to one shared counter) and the cached launch is dropped."""
         for g, fast in list(self._fast.items()):
             if gi is not None and g != gi:
                 continue
-            if fast[3]:
-                for p in fast[0]:
-                    self.state[p]["step"] += fast[3]
-                fast[3] = 0
-            if gi is not None:
-                del self._fast[g]
+            for p in fast["params"]:
+                st = self.state.get(p)
+                if st is not None and st.get("step") is fast["step_t"]:
+                    st["step"] = fast["step_t"].clone()
+            del self._fast[g]
 
+    # ------------------------------------------------------------------------------------------------------------
+    # (de)serialisation: torch.optim.AdamW's layout
+    # ------------------------------------------------------------------------------------------------------------
     def state_dict(self):
+        return super().state_dict()               # aliased `step` tensors serialise as equal values, one per parameter
+
+    def load_state_dict(self, state_dict):
+        """Resume: moments and step counts are replaced, so every cached pointer record and device counter is stale."""
         self._sync_fast_steps()
-        return super().state_dict()
+        super().load_state_dict(state_dict)
+        self._drop_caches()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # in-place snapshot / restore (hipGraph capture needs eager warm-up steps that must not advance the run)
+    # ------------------------------------------------------------------------------------------------------------
+    def snapshot(self):
+        """Copies of every state tensor (moments, step counts), keyed by parameter."""
+        return {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.state.items()}
+
+    @torch.no_grad()
+    def restore(self, snap):
+        """Write a snapshot() back IN PLACE: moments keep their addresses, so pointer tables, the fast path and a captured
+        graph stay valid; the device step counters are set to the restored count.  State created after the snapshot
+        (first warm-up step) is reset to zero moments / step 0, which is what a missing state means."""
+        for p, st in self.state.items():
+            old = snap.get(p)
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if old is not None:
+                        v.copy_(old[k])           # aliased `step` counters: every alias restores the same value
+                    else:
+                        v.zero_()
+        for gi, fast in list(self._fast.items()):
+            steps = {int(self.state[p]["step"].item()) for p in fast["params"]}
+            if len(steps) != 1:
+                self._drop_caches()
+                return
+            n = steps.pop()
+            fast["step_dev"].copy_(torch.tensor([n, 0], dtype=torch.int64))
+            for ent in self._step_dev.values():
+                if ent[1] is fast["step_dev"]:
+                    ent[0] = n
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_fast"):
+            self._drop_caches()

@@ -35,11 +35,35 @@ class GradAllReduce:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def shard_rows(n_rows, rank, world):
-    """Contiguous row range [lo, hi) of `rank` (rank r gets rows r*B..(r+1)*B)."""
+def shard_rows(n_rows, rank, world, equal=False):
+    """Contiguous row range [lo, hi) of `rank` (rank r gets rows r*B..(r+1)*B).
+    equal=True: every rank gets floor(n_rows / world) rows (the remainder is dropped, like drop_last): a training loop
+    whose ranks run different numbers of steps would leave the others waiting in the gradient all-reduce forever."""
+    if equal:
+        per = n_rows // world
+        return rank * per, (rank + 1) * per
     per = (n_rows + world - 1) // world
     lo = min(n_rows, rank * per)
     return lo, min(n_rows, lo + per)
+
+
+def average_bn_buffers(model, group=None):
+    """BatchNorm running statistics are per shard during training (no collective in the step); averaging them before
+    validation gives every rank the SAME eval-mode model, hence the same validation loss and the same scheduler /
+    early-stopping decisions.  2 x 896 floats at the default widths."""
+    world = dist.get_world_size(group)
+    with torch.no_grad():
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                buf.div_(world)
+
+
+def all_ranks_mean(value, device, group=None):
+    """Mean of a host float over the ranks (control-flow decisions must be taken on identical numbers everywhere)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)
 
 
 def attach(model, group=None, overlap=True):

@@ -19,5 +19,5 @@ def vae_loss(recon_a, a, recon_b, b, recon_c, site, mu, logvar, beta=1e-3, gamma
         # the reference ends in `recon.item()` / `class_loss.item()` on a Python int here
         raise AttributeError("'int' object has no attribute 'item'")
     total, out4 = F_.fused_loss(terms, float(beta), float(gamma), class_weights)
-    vals = out4.tolist()
+    vals = F_.read_losses(out4)
     return total, vals[1], vals[2], vals[3]

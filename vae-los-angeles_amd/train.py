@@ -98,7 +98,7 @@ def main():
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(Config.RANDOM_SEED))
     n_val = int(n * Config.TRAIN_TEST_SPLIT)
     val_idx, train_idx = perm[:n_val], perm[n_val:]
-    lo, hi = parallel.shard_rows(train_idx.numel(), rank, world)             # each rank owns a row shard
+    lo, hi = parallel.shard_rows(train_idx.numel(), rank, world, equal=True)  # each rank owns a row shard of the SAME size: same step count
     tr = [t[train_idx[lo:hi]].to(dev) for t in (tpm, beta_v, site)]
     va = [t[val_idx].to(dev) for t in (tpm, beta_v, site)]
     class_weights = balanced_class_weights(site[train_idx], args.n_sites).to(dev)
@@ -132,6 +132,8 @@ def main():
             running += loss.item()
             steps += 1
         dt = time.time() - t0
+        if world > 1:
+            parallel.average_bn_buffers(model)                                # same eval-mode model on every rank
         model.eval()
         val_loss, vsteps = 0.0, 0
         with torch.no_grad():
@@ -143,6 +145,11 @@ def main():
                 val_loss += loss.item()
                 vsteps += 1
         val_loss /= max(vsteps, 1)
+        if world > 1:
+            # eps is sampled in eval mode too (vae.py:73) and the Philox streams differ per rank: the scheduler / checkpoint /
+            # early-stop decisions below must see ONE number on every rank or the ranks part ways (different LR, or a rank
+            # leaving the loop while the others wait in the all-reduce)
+            val_loss = parallel.all_ranks_mean(val_loss, dev)
         scheduler.step(val_loss)
         if rank == 0:
             print(f"Epoch [{epoch + 1}/{args.epochs}] | Train Loss: {running / max(steps, 1):.2f} | Val Loss: {val_loss:.2f} | "
