@@ -200,9 +200,9 @@ int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* args, void* stream);
  *   sums[3] += -0.5 * sum(1 + lv - mu^2 - exp(lv))              (losses.py:42)
  *   sums[4] += number of labels outside [0, S)  (torch's cross_entropy device-asserts on them; here such a row is
  *              computed as class 0 and COUNTED: the host wrapper raises when the count it reads back is not 0)
- * `sums` is double[5], zeroed by the caller.  out5 / ticket (both or neither; ticket is one zeroed uint32): the block that
- * finishes last writes out5 = {s0+s1 + gamma*s2 + beta*s3, s0+s1, s2, s3, s4} as floats (the tuple of losses.py:44,46) and
- * re-arms the ticket -- no separate mmvae_loss_finalize launch.  Gradients of total = s0+s1+gamma*s2+beta*s3:
+ * `sums` is double[5], zeroed by the caller; mmvae_loss_finalize turns it into the tuple of losses.py:44,46 (a last-block
+ * finalisation inside the kernel was measured: ~1000 tickets on one address + the fences cost 50 us against a 5 us launch).
+ * Gradients of total = s0+s1+gamma*s2+beta*s3:
  *   g_a = 2(recon_a-a) ; g_b = (p-b)/max(p(1-p),1e-12)  [grad_b_wrt_logit: times p(1-p)] ;
  *   g_c = gamma*w[y]*(softmax - onehot) ; g_mu = beta*mu ; g_lv = -0.5*beta*(1-exp(lv)).
  * ------------------------------------------------------------------------------------------- */
@@ -218,10 +218,9 @@ typedef struct {
     void* g_b; int32_t g_b_dtype; int64_t ld_gb; int32_t grad_b_wrt_logit;
     float* g_c; int64_t ld_gc;
     float* g_mu; float* g_lv;
-    float* out5; uint32_t* ticket;
 } mmvae_loss_args;
 int mmvae_vae_loss(const mmvae_loss_args* args, void* stream);
-/* out5 = {recon + gamma*class + beta*kld, recon, class, kld, bad labels} (float) from sums[5]: stand-alone form of the tail. */
+/* out5 = {recon + gamma*class + beta*kld, recon, class, kld, labels out of range} (float) from sums[5]. */
 int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out5, void* stream);
 
 /* out = g * p * (1-p): Sigmoid backward for gradients that arrive w.r.t. recon_b (decoders.py:32). */
@@ -242,10 +241,12 @@ int mmvae_scale_many(const mmvae_scale_item* items_host, int32_t n_items, const 
  * ------------------------------------------------------------------------------------------- */
 /* One launch: n_mask keep-mask bytes (P(1) = keep_prob) and n_eps standard normals.  The Philox counter starts at
  * offset + *offset_dev (offset_dev may be NULL); a device-resident offset lets a captured hipGraph draw fresh noise on
- * every replay.  The call consumes ceil(n_mask/16)*4 + ceil(n_eps/4) counter values; with advance_ticket != NULL (one
- * zeroed uint32 next to the counter) the launch itself adds that amount to *offset_dev once all its blocks have read it. */
+ * every replay.  The call consumes ceil(n_mask/16)*4 + ceil(n_eps/4) counter values.  advance != 0: offset_dev is an array of
+ * MMVAE_CTR_COPIES identical copies of the counter (block L reads copy L; no block reads a word another one writes) and the
+ * launch itself moves every copy past what it consumed -- no separate counter launch. */
+#define MMVAE_CTR_COPIES 16384
 int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed, uint64_t offset,
-                uint64_t* offset_dev, uint32_t* advance_ticket, void* stream);
+                uint64_t* offset_dev, int32_t advance, void* stream);
 int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /* *counter_dev += inc */
 
 /* ---------------------------------------------------------------------------------------------
@@ -257,10 +258,10 @@ int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } mmvae_adamw_item;
 int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                     uint64_t* step_dev, uint32_t* advance_ticket, void* stream);
+                     uint64_t* step_dev, int32_t advance, void* stream);
 /* step_dev != NULL: bias corrections are computed in the kernel from t = *step_dev + 1 (graph-capturable) and
- * bias_corr1/2 are ignored.  advance_ticket != NULL (one zeroed uint32; n_items <= 64): the launch increments *step_dev
- * itself once every block has read it; otherwise advance the counter with mmvae_counter_add after the launch. */
+ * bias_corr1/2 are ignored.  advance != 0 (n_items <= 64): step_dev holds MMVAE_CTR_COPIES identical copies of the count and
+ * the launch increments all of them itself (see mmvae_noise); otherwise advance the counter with mmvae_counter_add. */
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,8 @@ def test_argument_checks_reject_before_launch():
     b = _lib.BnFinalizeArgs()
     b.M, b.N = 1, 8                        # BatchNorm1d training needs > 1 row
     assert lib.mmvae_bn_finalize(C.byref(b), None) == -1
-    assert lib.mmvae_adamw_step(None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 0, None, None, None) == -1
-    assert lib.mmvae_noise(None, 0, 0.9, None, 0, 1, 0, None, None, None) == -1
+    assert lib.mmvae_adamw_step(None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 0, None, 0, None) == -1
+    assert lib.mmvae_noise(None, 0, 0.9, None, 0, 1, 0, None, 0, None) == -1
     la = _lib.LossArgs()
     la.B = 4                               # no accumulator buffer
     assert lib.mmvae_vae_loss(C.byref(la), None) == -1

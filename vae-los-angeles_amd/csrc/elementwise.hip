@@ -420,27 +420,6 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
         const double v = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
         if (v != 0.0) unsafeAtomicAdd(a.sums + threadIdx.x, v);
     }
-    if (a.out5 == nullptr) return;
-    // The block whose ticket is the last one turns the five sums into the tuple the reference returns (losses.py:44,46): no
-    // separate finalize launch.  Every block's sums are device-scope atomics that complete (vmcnt) before its fence and ticket;
-    // the last block reads them back with returning atomics (performed where the adds were performed, never a cached copy).
-    __shared__ unsigned last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        double t[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) t[k] = atomicAdd(a.sums + k, 0.0);
-        const double recon = t[0] + t[1];
-        a.out5[0] = (float)(recon + (double)a.gamma * t[2] + (double)a.beta * t[3]);
-        a.out5[1] = (float)recon; a.out5[2] = (float)t[2]; a.out5[3] = (float)t[3]; a.out5[4] = (float)t[4];
-        *a.ticket = 0u;                                    // ready for the next launch (hipGraph replays re-run the memset anyway)
-    }
 }
 
 // out = {total, recon, class, kld, labels out of range} as the reference returns them (losses.py:44,46); stand-alone form of the
@@ -514,24 +493,27 @@ __device__ __forceinline__ void randn_quad(float* out, long n, long q, uint64_t 
 }
 
 // one launch for all dropout masks (one contiguous uint8 buffer) and eps of a forward pass
-// Last-block-done: every block draws a ticket AFTER it has read the device-resident counter; the block that draws the last
-// one advances the counter for the next launch and re-arms the ticket.  Replaces a 1-thread mmvae_counter_add launch per step.
-__device__ __forceinline__ void advance_counter_when_all_blocks_read(uint64_t* counter, uint64_t inc, unsigned* ticket, unsigned nblocks) {
-    __syncthreads();                                  // this block's threads hold the old value in registers
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        if (atomicAdd(ticket, 1u) == nblocks - 1) { *counter += inc; *ticket = 0u; }
-    }
+// Device-resident counters that a launch both reads and advances (Philox offset, Adam step count) are kept as MMVAE_CTR_COPIES
+// identical copies: block L reads copy L and, when it is done, rewrites the copies L, L + nblocks, ... with the advanced value.
+// No block ever reads a word another block writes, so there is no ordering to enforce, no ticket and no extra launch
+// (a 1-thread counter launch costs ~4 us + a kernel boundary; a last-block ticket costs ~45 ns per block on ONE address).
+__device__ __forceinline__ uint64_t ctr_read(const uint64_t* copies, unsigned L) { return copies[L % MMVAE_CTR_COPIES]; }
+__device__ __forceinline__ void ctr_advance(uint64_t* copies, unsigned L, unsigned nblocks, uint64_t value) {
+    __syncthreads();                                  // every thread of the block holds the old value
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        for (unsigned e = L; e < MMVAE_CTR_COPIES; e += nblocks) copies[e] = value;
 }
 
 __global__ __launch_bounds__(256) void noise_kernel(uint8_t* mask, long n_mask, float* eps, long n_eps, uint32_t thresh,
-                                                    uint64_t seed, uint64_t offset, uint64_t* offset_dev, uint64_t advance, unsigned* ticket) {
-    if (offset_dev) offset += *(volatile uint64_t*)offset_dev;
+                                                    uint64_t seed, uint64_t offset, uint64_t* offset_dev, uint64_t advance, int copies) {
+    const uint64_t base = offset_dev ? (copies ? ctr_read(offset_dev, blockIdx.x) : *offset_dev) : 0;
+    offset += base;
     const long nqm = (n_mask + 15) / 16, nqe = (n_eps + 3) / 4;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nqm + nqe; q += (long)gridDim.x * blockDim.x) {
         if (q < nqm) mask_quad(mask, n_mask, q, thresh, seed, offset);
         else randn_quad(eps, n_eps, q - nqm, seed, offset + (uint64_t)nqm * 4);
     }
-    if (ticket) advance_counter_when_all_blocks_read(offset_dev, advance, ticket, gridDim.x);
+    if (copies) ctr_advance(offset_dev, blockIdx.x, gridDim.x, base + advance);
 }
 
 __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
@@ -543,10 +525,13 @@ struct AdamWBatch { mmvae_adamw_item items[64]; };      // passed BY VALUE (2.5 
                                                         // so the launch is hipGraph-capturable even when gradients move
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, float lr, float b1, float b2,
                                                      float eps, float wd, float bc1, float rsqrt_bc2, int maximize,
-                                                     uint64_t* step_dev, unsigned* ticket) {
+                                                     uint64_t* step_dev, int copies) {
     const mmvae_adamw_item it = batch.items[blockIdx.y];
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;
+    uint64_t steps_done = 0;
     if (step_dev) {                                 // graph-capturable form: step count lives on the device
-        const float t = (float)(*(volatile uint64_t*)step_dev + 1);
+        steps_done = copies ? ctr_read(step_dev, L) : *step_dev;
+        const float t = (float)(steps_done + 1);
         bc1 = 1.f - powf(b1, t);
         rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
     }
@@ -560,7 +545,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, floa
         p -= step * m / (sqrtf(v) * rsqrt_bc2 + eps);
         it.p[i] = p; it.m[i] = m; it.v[i] = v;
     }
-    if (ticket) advance_counter_when_all_blocks_read(step_dev, 1, ticket, gridDim.x * gridDim.y);
+    if (copies) ctr_advance(step_dev, L, gridDim.x * gridDim.y, steps_done + 1);
 }
 
 static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
@@ -574,7 +559,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 10; }
+extern "C" int mmvae_abi_version(void) { return 11; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -696,7 +681,6 @@ extern "C" int mmvae_vae_loss(const mmvae_loss_args* a, void* stream) {
     if (a->recon_b && (!a->b || a->D <= 0)) return MMVAE_ERR_ARG;
     if (a->logits && (!a->site || a->S <= 0)) return MMVAE_ERR_ARG;
     if (a->mu && (!a->logvar || a->L <= 0)) return MMVAE_ERR_ARG;
-    if ((a->out5 != nullptr) != (a->ticket != nullptr)) return MMVAE_ERR_ARG;
     if ((long)a->B * (a->A > a->D ? a->A : a->D) >= (1L << 32)) return MMVAE_ERR_ARG;
     const int gdt = a->g_a ? a->g_a_dtype : a->g_b_dtype;
     if (a->g_a && a->g_b && a->g_a_dtype != a->g_b_dtype) return MMVAE_ERR_DTYPE;
@@ -761,14 +745,14 @@ extern "C" int mmvae_scale_if_needed(void* x, int32_t dtype, int64_t n, const fl
 }
 
 extern "C" int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int64_t n_eps, uint64_t seed,
-                           uint64_t offset, uint64_t* offset_dev, uint32_t* advance_ticket, void* stream) {
+                           uint64_t offset, uint64_t* offset_dev, int32_t advance, void* stream) {
     if ((n_mask > 0 && (!mask || ((uintptr_t)mask & 15))) || (n_eps > 0 && !eps) || n_mask < 0 || n_eps < 0 || n_mask + n_eps == 0 ||
-        keep_prob < 0.f || keep_prob > 1.f || (advance_ticket && !offset_dev)) return MMVAE_ERR_ARG;
-    const uint64_t advance = (uint64_t)((n_mask + 15) / 16 * 4 + (n_eps + 3) / 4);       // counter values this call consumes
+        keep_prob < 0.f || keep_prob > 1.f || (advance && !offset_dev)) return MMVAE_ERR_ARG;
+    const uint64_t used = (uint64_t)((n_mask + 15) / 16 * 4 + (n_eps + 3) / 4);       // counter values this call consumes
     const double t = (double)keep_prob * 4294967296.0;
     const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     hipLaunchKernelGGL(noise_kernel, dim3(grid_for((n_mask + 15) / 16 + (n_eps + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       mask, n_mask, eps, n_eps, thresh, seed, offset, offset_dev, advance, advance_ticket);
+                       mask, n_mask, eps, n_eps, thresh, seed, offset, offset_dev, used, advance ? 1 : 0);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -782,9 +766,9 @@ extern "C" int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stre
 
 extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                                uint64_t* step_dev, uint32_t* advance_ticket, void* stream) {
+                                uint64_t* step_dev, int32_t advance, void* stream) {
     if (!items_host || n_items <= 0 || (!step_dev && (bias_corr1 <= 0.f || bias_corr2 <= 0.f))) return MMVAE_ERR_ARG;
-    if (advance_ticket && (!step_dev || n_items > 64)) return MMVAE_ERR_ARG;       // one launch = one tick of the counter
+    if (advance && (!step_dev || n_items > 64)) return MMVAE_ERR_ARG;       // one launch = one tick of the counter
     if (step_dev) { bias_corr1 = 1.f; bias_corr2 = 1.f; }
     for (int base = 0; base < n_items; base += 64) {
         AdamWBatch batch;
@@ -797,7 +781,7 @@ extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_it
         }
         const int gx = grid_for(max_numel, 256 * 4, 256);
         hipLaunchKernelGGL(adamw_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, batch, lr, beta1, beta2, eps,
-                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev, advance_ticket);
+                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev, advance ? 1 : 0);
         MM_CHECK_LAUNCH();
     }
     return 0;

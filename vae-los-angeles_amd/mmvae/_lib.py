@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -17,6 +17,7 @@ PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY = 0, 1, 2
 EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TILE = 128
+CTR_COPIES = 16384      # MMVAE_CTR_COPIES: self-advancing device counters are stored as this many identical int64 copies
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -96,7 +97,7 @@ class LossArgs(C.Structure):
                 ("g_a", vp), ("g_a_dtype", i32), ("ld_ga", i64),
                 ("g_b", vp), ("g_b_dtype", i32), ("ld_gb", i64), ("grad_b_wrt_logit", i32),
                 ("g_c", vp), ("ld_gc", i64),
-                ("g_mu", vp), ("g_lv", vp), ("out5", vp), ("ticket", vp)]
+                ("g_mu", vp), ("g_lv", vp)]
 
 
 class AdamWItem(C.Structure):
@@ -122,9 +123,9 @@ _SIGNATURES = {
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
     "mmvae_scale_many": [C.POINTER(ScaleItem), i32, vp, vp],
-    "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, vp, vp],
+    "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, i32, vp],
     "mmvae_counter_add": [vp, C.c_uint64, vp],
-    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, i32, vp],
 }
 EXPORTED = ["mmvae_abi_version"] + sorted(_SIGNATURES)
 

@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import ops
+from . import _lib as L_
 from .ops import (PREC_BF16, PREC_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, EPI_RELU_MASK, EPI_BN_BWD, TILE, DROP_P,
                   ceil_to, act_dtype)
 
@@ -61,7 +62,7 @@ class NoiseSource:
     def offset_tensor(self, device):
         t = self._offsets.get(device)
         if t is None:
-            t = self._offsets[device] = torch.zeros(2, dtype=torch.int64, device=device)     # [Philox offset, ticket of the advancing launch]
+            t = self._offsets[device] = torch.zeros(L_.CTR_COPIES, dtype=torch.int64, device=device)    # identical copies, see mmvae_noise
         return t
 
     def state_dict(self, device):
@@ -71,8 +72,7 @@ class NoiseSource:
 
     def load_state_dict(self, state, device):
         device = torch.device(device) if not isinstance(device, torch.device) else device
-        t = self.offset_tensor(device)
-        t.copy_(torch.tensor([int(state["offset"]), 0], dtype=torch.int64))
+        self.offset_tensor(device).fill_(int(state["offset"]))
 
     def draw(self, B, widths, Ld, device):
         """-> ([uint8 (B,w) keep-mask for w in widths], eps fp32 (B,Ld) or None if Ld is None)."""

@@ -222,7 +222,7 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
     ra_, a_, rb_, b_, lg_, mu_, lv_ = (prep(ra), prep(a), prep(rb), prep(b), prep(lg), prep(mu), prep(lv))
     if mu_ is not None:
         mu_, lv_ = mu_.contiguous(), lv_.contiguous()
-    sums, ticket, out4 = ops.loss_workspace(dev)          # out4: [total, recon, class, kld, labels out of range]
+    sums, out4 = ops.loss_workspace(dev)                  # out4: [total, recon, class, kld, labels out of range]
 
     # ---- fused hand-off: all differentiable inputs are outputs of ONE forward of our model --------------------
     tags = [_tag_of(t) for t in (ra, rb, lg, mu, lv) if t is not None and t.requires_grad]
@@ -245,8 +245,8 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         g_mu = torch.empty(B, mu.shape[1], dtype=torch.float32, device=dev) if mu is not None else None
         g_lv = torch.empty_like(g_mu) if mu is not None else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv,
-                     out5=out4, ticket=ticket)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv)
+        ops.loss_finalize(sums, beta, gamma, out4)
         stash = {"g_outs": g_outs, "g_mu": g_mu, "g_lv": g_lv, "scale": None, "unit_grad": bool(unit_grad)}
         if g_mu is None:                       # KL term absent: nothing flows into mu/logvar from this loss
             stash["g_mu"] = torch.zeros(B, saved["logvar"].shape[1], dtype=torch.float32, device=dev)
@@ -265,8 +265,8 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         gm = torch.empty_like(mu_) if (need_grad and mu is not None and mu.requires_grad) else None
         gl = torch.empty_like(lv_) if (need_grad and lv is not None and lv.requires_grad) else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl,
-                     out5=out4, ticket=ticket)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl)
+        ops.loss_finalize(sums, beta, gamma, out4)
         grads = []
         for t, g in ((ra, ga), (rb, gb), (lg, gc), (mu, gm), (lv, gl)):
             if t is not None:

@@ -337,16 +337,15 @@ def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_tabl
 
 
 def loss_workspace(device):
-    """-> (sums float64[5], ticket, out5 float32[5]) from ONE zero-filled allocation (one memset): the accumulators of
-    mmvae_vae_loss, the ticket of its in-kernel finalisation and the tuple it leaves behind."""
-    buf = torch.zeros(5 * 8 + 8 + 5 * 4 + 4, dtype=torch.uint8, device=device)
-    return buf[:40].view(torch.float64), buf[40:48].view(torch.int32), buf[48:68].view(torch.float32)
+    """-> (sums float64[5] zeroed, out5 float32[5]): the accumulators of mmvae_vae_loss and the tuple mmvae_loss_finalize makes of them."""
+    buf = torch.zeros(5 * 8 + 5 * 4 + 4, dtype=torch.uint8, device=device)
+    return buf[:40].view(torch.float64), buf[40:60].view(torch.float32)
 
 
 def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site=None, class_weights=None,
              mu=None, logvar=None, beta=1e-3, gamma=1.0, sums=None, g_a=None, g_b=None, grad_b_wrt_logit=False,
-             g_c=None, g_mu=None, g_lv=None, out5=None, ticket=None):
-    """sums: zeroed float64[5].  out5 + ticket (loss_workspace): the launch also writes the finalised tuple."""
+             g_c=None, g_mu=None, g_lv=None):
+    """sums: zeroed float64[5] (four loss sums + the count of labels outside [0, S))."""
     x = L.LossArgs()
     x.B = B
     if recon_a is not None:
@@ -366,7 +365,6 @@ def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site
         x.g_c, x.ld_gc = g_c.data_ptr(), _ld(g_c)
     x.g_mu, x.g_lv = _p(g_mu), _p(g_lv)
     assert sums.dtype == torch.float64 and sums.numel() >= 5
-    x.out5, x.ticket = _p(out5), _p(ticket)
 
     def nbytes():
         n = 0
@@ -406,15 +404,13 @@ def scale_if_needed(x, scale):
 def noise(mask, eps, keep_prob, seed, offset, offset_dev=None, advance=False):
     """Fill `mask` (uint8, any shape, contiguous; may be None) and `eps` (fp32; may be None) from the Philox stream
     (seed, offset [+ *offset_dev]).  Returns the number of counter values consumed.  advance=True: offset_dev is an
-    int64[2] tensor (counter, zeroed ticket) and the launch itself moves the counter past what it consumed."""
+    int64[CTR_COPIES] tensor of identical copies of the counter and the launch itself moves them past what it consumed."""
     n_mask = 0 if mask is None else mask.numel()
     n_eps = 0 if eps is None else eps.numel()
-    ticket = None
     if advance:
-        assert offset_dev is not None and offset_dev.numel() >= 2
-        ticket = offset_dev.data_ptr() + 8
+        assert offset_dev is not None and offset_dev.numel() == L.CTR_COPIES and offset_dev.dtype == torch.int64
     with probe_span("noise", n_mask + 4 * n_eps):
-        L.check(L.load().mmvae_noise(_p(mask), n_mask, keep_prob, _p(eps), n_eps, seed, offset, _p(offset_dev), ticket, _stream()), "mmvae_noise")
+        L.check(L.load().mmvae_noise(_p(mask), n_mask, keep_prob, _p(eps), n_eps, seed, offset, _p(offset_dev), int(advance), _stream()), "mmvae_noise")
     return (n_mask + 15) // 16 * 4 + (n_eps + 3) // 4
 
 
@@ -431,12 +427,14 @@ def counter_add(counter, inc):
 
 
 def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=None):
-    """items: ctypes array of AdamWItem in host memory (device pointers inside).  step_dev: int64[2] tensor (step count,
-    zeroed ticket): bias corrections from the device counter, which the launch itself increments (<= 64 tensors; beyond
-    that one mmvae_counter_add follows the launches)."""
+    """items: ctypes array of AdamWItem in host memory (device pointers inside).  step_dev: int64[CTR_COPIES] tensor of
+    identical copies of the step count: bias corrections from the device counter, which the launch itself increments
+    (<= 64 tensors; beyond that the copies are advanced by a fill after the launches)."""
     tick = step_dev is not None and len(items) <= 64
+    if step_dev is not None:
+        assert step_dev.numel() == L.CTR_COPIES and step_dev.dtype == torch.int64
     with probe_span("adamw", lambda: 28 * sum(it.n for it in items)):
         L.check(L.load().mmvae_adamw_step(C.cast(items, C.c_void_p), len(items), lr, b1, b2, eps, wd, bc1, bc2, int(maximize),
-                                          _p(step_dev), (step_dev.data_ptr() + 8) if tick else None, _stream()), "mmvae_adamw_step")
+                                          _p(step_dev), int(tick), _stream()), "mmvae_adamw_step")
     if step_dev is not None and not tick:
-        counter_add(step_dev, 1)
+        step_dev.add_(1)

@@ -32,7 +32,7 @@ class FusedAdamW(torch.optim.Optimizer):
     # ------------------------------------------------------------------------------------------------------------
     def _drop_caches(self):
         self._tables = {}             # key id -> (pointer key, ctypes records)
-        self._step_dev = {}           # (group / bucket, device) -> [host mirror of the count, int64[2] device (count, ticket)]
+        self._step_dev = {}           # (group / bucket, device) -> [host mirror of the count, int64[CTR_COPIES] device copies]
         self._fast = {}               # group index -> dict(params, key, items, pending, step_dev)
 
     @staticmethod
@@ -51,11 +51,12 @@ class FusedAdamW(torch.optim.Optimizer):
         return items, key
 
     def _device_step(self, key, bucket_step, device):
-        """Device counter holding (steps already applied) for the parameters of this bucket: int64[2] = (count, ticket)."""
+        """Device counter holding (steps already applied) for the parameters of this bucket: CTR_COPIES identical int64
+        copies (mmvae_adamw_step advances them itself, one copy per block)."""
         k = (key, str(device))
         ent = self._step_dev.get(k)
         if ent is None or ent[0] != bucket_step - 1:
-            t = torch.tensor([bucket_step - 1, 0], dtype=torch.int64, device=device)
+            t = torch.full((L.CTR_COPIES,), bucket_step - 1, dtype=torch.int64, device=device)
             ent = [bucket_step - 1, t]
             self._step_dev[k] = ent
         ent[0] = bucket_step
@@ -224,7 +225,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._drop_caches()
                 return
             n = steps.pop()
-            fast["step_dev"].copy_(torch.tensor([n, 0], dtype=torch.int64))
+            fast["step_dev"].fill_(n)
             for ent in self._step_dev.values():
                 if ent[1] is fast["step_dev"]:
                     ent[0] = n
