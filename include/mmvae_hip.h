@@ -117,6 +117,14 @@ typedef struct {
     const void* p_y; int64_t ld_py; const float* p_mean; const float* p_rstd; const float* p_coef;
 } mmvae_gemm_tn_args;
 int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
+/* Up to MMVAE_TN_GROUP_MAX small-output problems (same prec; the latent / class-width layers: encoder heads, decoder first
+ * layers, DecoderC) in ONE GEMM launch + ONE reduce launch: alone each is a latency chain of ~25 us for a few MB.  Every
+ * problem needs a slab workspace of its own (MMVAE_TN_GROUP_SPLITS * N * K floats covers any split), lddw == K and no P prologue; operand
+ * combinations: P f32 with Q through the BN+ReLU+Dropout prologue, P and Q activation-typed, P f32 with Q activation-typed.
+ * Returns MMVAE_ERR_ARG when a problem does not fit: launch that one with mmvae_gemm_tn. */
+#define MMVAE_TN_GROUP_MAX 8
+#define MMVAE_TN_GROUP_SPLITS 256
+int mmvae_gemm_tn_group(const mmvae_gemm_tn_args* args, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d, training mode (encoders.py:14,32,36): from the column sums compute

@@ -20,6 +20,7 @@
 #include "mmvae_hip.h"
 #include "gemm_src.h"
 #include "gemm_nt_epi.h"
+#include "gemm_nt2.h"
 
 namespace mm {
 
@@ -291,8 +292,23 @@ static inline bool nt_wide_ok(int M, int N) {
     return !off && N % 256 == 0 && M >= g_wide_min_m;       // the prepared W has ceil128(N) rows: whole 256-column tiles only
 }
 
+template <typename T> struct IsPlainBf16 { static constexpr bool value = false; };
+template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool value = true; };
+
 template <typename CT, typename Src, typename Epi>
 static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
+        // second-generation kernel (gemm_nt2.h): operands that go into the MFMA as they are, at least two K steps
+        static const bool off = getenv("MMVAE_NO_NT2") != nullptr;      // A/B switch
+        // ... and for epilogues without operands of their own: with a saved activation / keep mask to fetch, the epilogue's loads
+        // queue behind the next tile's DMA and its stores in front of the next wait (one in-order vmcnt for everything): measured
+        // 5-20 % SLOWER than the first generation there, 5-10 % faster on the plain store epilogues (tools/bench_nt2.py)
+        if (!off && K > 64 && !epi.accumulate_requested() && Epi::NEED == 0) {
+            static const bool narrow = getenv("MMVAE_NT2_NARROW") != nullptr;      // A/B switch: 128x128 tiles only
+            if (!narrow && nt_wide_ok(M, N)) return launch_nt2<Epi, 4>(src.p, src.lda, W, ldw, M, N, K, epi, st);
+            return launch_nt2<Epi, 2>(src.p, src.lda, W, ldw, M, N, K, epi, st);
+        }
+    }
     if constexpr (sizeof(CT) == 2) {
         if (nt_wide_ok(M, N) && !epi.accumulate_requested()) return launch_nt_wn<CT, Src, Epi, 4>(src, W, ldw, M, N, K, epi, st);
     }

@@ -1,0 +1,179 @@
+// NT GEMM, second generation (gfx950):  C[M,N] = epilogue( A[M,K] * W[N,K]^T )  for operands that need no arithmetic on their way
+// into the MFMA -- A already in the compute type (bf16 activations / gradients), W the prepared bf16 weights.
+//
+// What the first-generation kernel (gemm_nt.hip) spends its time on at B = 65 536 (tools/stamp_nt.py):
+//   * a tile's first loads are issued when the workgroup starts and its last stores when it ends; every workgroup of the launch
+//     runs the same program on the same amount of data, so the whole chip sits in its prologue (HBM saturated, MFMA idle), then
+//     in its main loops, then in its epilogues (HBM read path idle) together: 20-25 % of a workgroup's life on either side of
+//     an 8-13 step main loop;
+//   * operands travel global -> VGPR -> LDS: ~100 VGPRs of look-ahead and a registers -> LDS pass per K step that the MFMAs wait for.
+// This kernel:
+//   * moves both operands with LDS-DMA (global_load_lds_dwordx4: no VGPR destination, no ds_write pass); the XOR swizzle of the
+//     LDS image is applied to the per-lane SOURCE address (the LDS side of a DMA is lane-linear), 8 rows x one full 128-byte
+//     line per wave-instruction;
+//   * is PERSISTENT: a workgroup walks a list of tiles and treats (tile, K step) as one continuous stream of ring slots, so the
+//     DMA of the next tile's first K step is in flight while the current tile's epilogue runs -- no per-tile load prologue;
+//   * keeps the first generation's fragment layout (same LDS image, same swapped-operand MFMA order), hence its epilogues
+//     (gemm_nt_epi.h) unchanged: BatchNorm statistics, ReLU masks, BatchNorm backward, full-line stores.
+// Ring: 2 slots of {A [128][128 B], W [64*WN][128 B]}; per K step: wait for the own DMA of the slot (vmcnt), ONE barrier (every
+// wave's DMA has landed and every wave has finished reading the other slot), issue the DMA of the next step into the other slot,
+// multiply the current one.
+#pragma once
+#include "common.h"
+#include "gemm_nt_epi.h"
+
+namespace mm {
+
+template <int WN> struct Nt2Lds {
+    static constexpr int A_BYTES = TILE * ROW_BYTES;               // 16 KiB
+    static constexpr int W_BYTES = 64 * WN * ROW_BYTES;            // 8 KiB * WN
+    static constexpr int SLOT = A_BYTES + W_BYTES;
+    static constexpr int RING = 2 * SLOT;
+    static constexpr int RED = RING;                               // column-sum scratch of STATS epilogues: 4 * 64*WN floats
+    static constexpr int ECOL = RED + 4 * 64 * WN * 4;             // per-column constants of the epilogue: 8 * 64*WN floats
+    static constexpr int TOTAL = ECOL + 8 * 64 * WN * 4;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <typename Epi, int WN>
+__global__ __launch_bounds__(128 * WN, 2)
+void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, int stagger, Epi epi)
+{
+    typedef bf16 CT;
+    constexpr int BK = 64, BN = 64 * WN, NW = 2 * WN;
+    constexpr int A_PIECES = TILE / 8, W_PIECES = BN / 8;          // 1 KiB pieces (8 rows x 128 B) per slot
+    constexpr int A_PER = A_PIECES / NW, W_PER = W_PIECES / NW;
+    typedef Mma<CT>::frag frag;
+    typedef EpiCols<sizeof(typename Epi::out_t) == 2> EC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = (float*)(smem + Nt2Lds<WN>::RED);
+    float* ecol = (float*)(smem + Nt2Lds<WN>::ECOL);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid / WN, wc = wid % WN;
+    const int nk = (K + BK - 1) / BK;
+    const int kmax = ((K + 7) & ~7) - 8;                           // last 16-byte chunk that lies inside an A row (rows are padded to 8)
+    const int ntiles = ((gx + 7) / 8) * 8 * gy;                    // tile ids incl. the padding of gx to a multiple of 8
+
+    // tile id T -> (row tile, column tile): ids that differ by 8 run on one XCD; the column tiles of a row tile are adjacent there
+    auto tile_rc = [&](int T, int& rt, int& ct) { const int slot = T >> 3; ct = slot % gy; rt = (slot / gy) * 8 + (T & 7); };
+    auto next_tile = [&](int T) {
+        for (T += gridDim.x; T < ntiles; T += gridDim.x) { int rt, ct; tile_rc(T, rt, ct); if (rt < gx) return T; }
+        return -1;
+    };
+    int T = blockIdx.x;
+    { int rt, ct; tile_rc(T, rt, ct); if (rt >= gx) T = next_tile(T); }
+    if (T < 0) return;
+    // Optional stagger (A/B knob): every other workgroup of an XCD starts late, so that co-resident workgroups -- and the chip as
+    // a whole -- are not all in their store-heavy epilogues (or all in their load-heavy main loops) at the same time.
+    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(32);
+    }
+
+    // DMA of one ring slot: lane l of a piece writes LDS (row = 8 p + l / 8, position l % 8) and reads chunk (position ^ (row & 7))
+    // of that row: the LDS image is the first generation's swz() image.
+    const int prow = lane >> 3, ppos = lane & 7;
+    auto issue = [&](int tile, int kt, int slot) {
+        int rt, ct; tile_rc(tile, rt, ct);
+        const int row0 = rt * TILE, col0 = ct * BN;
+        unsigned char* sA = smem + slot * Nt2Lds<WN>::SLOT;
+        unsigned char* sW = sA + Nt2Lds<WN>::A_BYTES;
+        const bf16* Ak = A + kt * BK;                               // wave-uniform part of the address
+        const bf16* Wk = W + kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int p = wid + NW * i, r = p * 8 + prow;
+            const int c = ppos ^ (r & 7);
+            const int kc = min(c * 8, kmax - kt * BK);              // chunks past the padded row end re-read its last chunk (x zero weights)
+            const unsigned off = (unsigned)min(row0 + r, M - 1) * (unsigned)lda + (unsigned)kc;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Ak + off), (lds_void*)(sA + p * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            const int p = wid + NW * i, r = p * 8 + prow;
+            const int c = ppos ^ (r & 7);
+            const int wrw = (r & ~63) + EC::wrow(r & 63);           // the epilogue's column order inside a wave's 64 columns (gemm_nt_epi.h)
+            const unsigned off = (unsigned)(col0 + wrw) * (unsigned)ldw + (unsigned)(c * 8);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Wk + off), (lds_void*)(sW + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+    frag f0a[4], f0b[4], f1a[4], f1b[4];
+    auto rd = [&](frag (&af)[4], frag (&bf)[4], int slot, int s) {
+        const unsigned char* sA = smem + slot * Nt2Lds<WN>::SLOT;
+        const unsigned char* sW = sA + Nt2Lds<WN>::A_BYTES;
+        const int ch = s * 4 + (lane >> 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { const int r = wr * 64 + m * 16 + (lane & 15); af[m] = *(const frag*)(sA + r * ROW_BYTES + ((ch ^ (r & 7)) << 4)); }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { const int r = wc * 64 + n * 16 + (lane & 15); bf[n] = *(const frag*)(sW + r * ROW_BYTES + ((ch ^ (r & 7)) << 4)); }
+    };
+    auto mma = [&](const frag (&af)[4], const frag (&bf)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], bf[n], af[m]);     // swapped operands: transposed accumulator (gemm_nt_epi.h)
+    };
+
+    issue(T, 0, 0);
+    int g = 0;                                                      // ring position: slot = g & 1, continuous across tiles
+    for (;;) {
+        const int Tn = next_tile(T);
+        int rt, ct; tile_rc(T, rt, ct);
+        const int row0 = rt * TILE, col0 = ct * BN;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        EpiOperands<Epi> eops;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // own DMA of this slot has landed (the only vector-memory operations in flight); after the barrier everybody's has,
+            // and nobody still reads the other slot
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt == 0) nt_epilogue_fill_cols<Epi, WN>(ecol, epi, col0, N, tid);     // previous tile's epilogue is over; visible after the next barrier
+            if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
+            else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);            // the next tile's first slot flies under this tile's epilogue
+            rd(f0a, f0b, g & 1, 0);
+            rd(f1a, f1b, g & 1, 1);
+            mma(f0a, f0b);
+            mma(f1a, f1b);
+        }
+        if (nk == 1) __syncthreads();                               // the column constants were written after this tile's only barrier
+        // epilogue operands (saved activation, keep mask): fetched here, not a K step early as the first generation does -- 48
+        // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
+        nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
+        nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+        if (Tn < 0) break;
+        T = Tn;
+    }
+}
+
+// Persistent grid: every CU gets its residency's worth of workgroups (2 of 4 waves, or 1 of 8), a multiple of 8 so that a
+// workgroup keeps to one XCD's tile list.
+template <typename Epi, int WN>
+static int launch_nt2(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt2_kernel<Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, Nt2Lds<WN>::TOTAL);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int gx = (M + TILE - 1) / TILE, gy = (N + 64 * WN - 1) / (64 * WN);
+    const int ntiles = ((gx + 7) / 8) * 8 * gy;
+    static const int wg_env = getenv("MMVAE_NT2_WGS") ? atoi(getenv("MMVAE_NT2_WGS")) : 0;      // A/B knob: workgroups per CU
+    const int per_cu = wg_env > 0 ? wg_env : (WN == 2 ? 2 : 1);
+    int grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    static const int stagger = getenv("MMVAE_NT2_STAGGER") ? atoi(getenv("MMVAE_NT2_STAGGER")) : 0;
+    hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN>), dim3(grid), dim3(128 * WN), Nt2Lds<WN>::TOTAL, st,
+                       (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, stagger, epi);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace mm

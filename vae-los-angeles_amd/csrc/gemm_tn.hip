@@ -71,20 +71,22 @@ __device__ unsigned long long mm_stamps_tn[12];
 #define MT_T(x)
 #endif
 
+// One workgroup's share of a dW GEMM: output tile and batch split from its LOCAL block id L (0 .. grid of this problem), shared
+// by the one-problem kernel and the grouped kernel below.
 template <typename CT, typename PSrc, typename QSrc>
-__global__ __launch_bounds__(NTHREADS, 2)
-void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
-                    int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
+__device__ __forceinline__
+void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
+             int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab,
+             const int L, unsigned char* smem)
 {
     typedef TnGeom<CT> G;
     constexpr int EPC = Mma<CT>::EPC;
     typedef typename Mma<CT>::frag frag;
     constexpr int BUF = 2 * G::MT * G::ROWB;                 // one batch step: P tile + Q tile (32 KiB)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
     float* aux = (float*)(smem + 2 * BUF);                   // Q prologue: BN scale / shift
     float* auxp = aux + 1024;                                // P prologue: BN-backward constants of this tile's 128 columns
 
-    const int L = blockIdx.x, slot = L >> 3;
+    const int slot = L >> 3;
     const int tile = slot % ntiles;
     const int zz = (slot / ntiles) * 8 + (L & 7);
     if (zz >= nsplit) return;
@@ -295,6 +297,76 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
 #endif
 }
 
+template <typename CT, typename PSrc, typename QSrc>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
+                    int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
+    tn_body<CT, PSrc, QSrc>(ps, qs, dW, ldw, db, M, N, K, ntk, ntiles, nsplit, rows_per_split, slab, (int)blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// Grouped launch: several SMALL-output dW GEMMs (latent / class widths: the heads of the encoders, the first layers of the
+// decoders, DecoderC) in ONE launch + ONE reduce.  Alone each of them is a latency chain (launch ramp, first loads, a few batch
+// steps, slab store, reduce launch: 22-29 us for a few MB), six of them took 157 us + 12 reduce launches of 6 us per step;
+// side by side their chains overlap.  Operand-type combinations a problem may have:
+//   0: P f32 (d_heads), Q activation type through the BatchNorm+ReLU+Dropout prologue   (encoder heads)
+//   1: P, Q activation type                                                               (decoder first layers)
+//   2: P f32 (loss gradient of the class logits), Q activation type                       (DecoderC.L1)
+// ------------------------------------------------------------------------------------------
+struct TnProblem {
+    int combo, M, N, K, ntk, ntiles, nsplit, rps, block0, nblocks;
+    float* dW; long ldw; float* db; float* slab;
+    const void* p; long ldp; const void* q; long ldq;
+    const float* pro_scale; const float* pro_shift; const uint8_t* pro_mask; long ld_pro_mask; float pro_inv_keep;
+};
+struct TnGroup { TnProblem pr[MMVAE_TN_GROUP_MAX]; int n; };
+
+template <typename CT>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_tn_group_kernel(const TnGroup g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MMVAE_TN_GROUP_MAX; ++i) if (i < g.n && (int)blockIdx.x >= g.pr[i].block0) pi = i;      // block ranges are ascending
+    const TnProblem& r = g.pr[pi];
+    const int L = (int)blockIdx.x - r.block0;
+    typedef SrcPlain<CT, float, 4> PF;
+    typedef SrcPlain<CT, CT, Mma<CT>::EPC> PA;          // activation-typed plain operand (EPC elements = 16 bytes)
+    if (r.combo == 0) {
+        const PF ps{(const float*)r.p, r.ldp, r.M, r.N};
+        const SrcBnReluDrop<CT> qs{(const CT*)r.q, r.ldq, r.M, r.K, r.pro_scale, r.pro_shift, r.pro_mask, r.ld_pro_mask, r.pro_inv_keep};
+        tn_body<CT>(ps, qs, r.dW, r.ldw, r.db, r.M, r.N, r.K, r.ntk, r.ntiles, r.nsplit, r.rps, r.slab, L, smem);
+    } else if (r.combo == 1) {
+        const PA ps{(const CT*)r.p, r.ldp, r.M, r.N};
+        const PA qs{(const CT*)r.q, r.ldq, r.M, r.K};
+        tn_body<CT>(ps, qs, r.dW, r.ldw, r.db, r.M, r.N, r.K, r.ntk, r.ntiles, r.nsplit, r.rps, r.slab, L, smem);
+    } else {
+        const PF ps{(const float*)r.p, r.ldp, r.M, r.N};
+        const PA qs{(const CT*)r.q, r.ldq, r.M, r.K};
+        tn_body<CT>(ps, qs, r.dW, r.ldw, r.db, r.M, r.N, r.K, r.ntk, r.ntiles, r.nsplit, r.rps, r.slab, L, smem);
+    }
+}
+
+// dW_p[n][k] += sum_z slab_p[z][n][k] for every problem of a group, fixed order (bitwise reproducible)
+struct TnGroupReduce { const float* slab[MMVAE_TN_GROUP_MAX]; float* dW[MMVAE_TN_GROUP_MAX]; int nsplit[MMVAE_TN_GROUP_MAX]; int nk[MMVAE_TN_GROUP_MAX];
+                       int first[MMVAE_TN_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupReduce g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.first[g.n]) return;
+    int pi = 0;
+#pragma unroll
+    for (int j = 1; j < MMVAE_TN_GROUP_MAX; ++j) if (j < g.n && i >= g.first[j]) pi = j;
+    const int e = i - g.first[pi], nk = g.nk[pi], ns = g.nsplit[pi];
+    const float* sl = g.slab[pi] + e;
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < ns; ++z) s += sl[(long)z * nk];
+    g.dW[pi][e] += s;                                    // lddw == K for these (contiguous gradient views)
+}
+
 #ifdef MM_STAMP
 extern "C" int mmvae_debug_stamps_tn(unsigned long long* out12, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(mm::mm_stamps_tn), 12 * sizeof(unsigned long long));
@@ -430,7 +502,91 @@ static int tn_dispatch_p(const mmvae_gemm_tn_args* a, hipStream_t st) {
     return tn_dispatch_q<CT>(a, p, st);
 }
 
+// host side of the grouped launch: classify every problem; -1 = not groupable (the caller launches it alone)
+template <typename CT>
+static int tn_group_combo(const mmvae_gemm_tn_args* a) {
+    constexpr int EPC = Mma<CT>::EPC;
+    const int act = sizeof(CT) == 2 ? MMVAE_BF16 : MMVAE_F32;
+    if (a->p_prologue != MMVAE_PRO_NONE || a->lddw != a->K || !a->slab) return -1;
+    const bool p_f32 = a->p_dtype == MMVAE_F32 && a->ldp % 4 == 0 && a->N % 4 == 0 && ((uintptr_t)a->p & 15) == 0;
+    const bool p_act = a->p_dtype == act && a->ldp % EPC == 0 && ((uintptr_t)a->p & 15) == 0 && (sizeof(CT) == 2 || a->N % 4 == 0);
+    const bool q_act = a->q_dtype == act && a->ldq % EPC == 0 && ((uintptr_t)a->q & 15) == 0 && (sizeof(CT) == 2 || a->K % 4 == 0);
+    if (a->q_prologue == MMVAE_PRO_BN_RELU_DROP) {
+        if (!p_f32 || !q_act || a->K > 512 || !a->pro_scale || !a->pro_shift) return -1;
+        if (a->pro_mask && (a->ld_pro_mask % 4 || ((uintptr_t)a->pro_mask & 3))) return -1;
+        return 0;
+    }
+    if (a->q_prologue != MMVAE_PRO_NONE || !q_act) return -1;
+    if (sizeof(CT) == 4) return p_f32 ? 1 : -1;           // f32 mode: every plain operand is f32
+    if (p_act) return 1;
+    return p_f32 ? 2 : -1;
+}
+
+template <typename CT>
+static int launch_tn_group(const mmvae_gemm_tn_args* args, int n, hipStream_t st) {
+    typedef TnGeom<CT> G;
+    TnGroup g; TnGroupReduce rd;
+    g.n = rd.n = n;
+    int block = 0, elems = 0;
+    // batch splits: ONE resident round for the whole group (2 workgroups per CU), at least 4 batch steps per workgroup
+    int tiles_total = 0;
+    for (int i = 0; i < n; ++i) tiles_total += ((args[i].N + TILE - 1) / TILE) * ((args[i].K + TILE - 1) / TILE);
+    int auto_split = (512 / tiles_total) & ~7;
+    if (auto_split < 8) auto_split = 8;
+    if (auto_split > MMVAE_TN_GROUP_SPLITS) auto_split = MMVAE_TN_GROUP_SPLITS;
+    for (int i = 0; i < n; ++i) {
+        const mmvae_gemm_tn_args* a = &args[i];
+        TnProblem& r = g.pr[i];
+        r.combo = tn_group_combo<CT>(a);
+        if (r.combo < 0) return MMVAE_ERR_ARG;
+        int want = a->nsplit > 0 ? a->nsplit : auto_split;
+        const int max_split = (a->M + 4 * G::MT - 1) / (4 * G::MT);
+        if (want > max_split) want = max_split;
+        if (want > MMVAE_TN_GROUP_SPLITS) want = MMVAE_TN_GROUP_SPLITS;
+        if (want < 1) want = 1;
+        tn_split(a->M, a->N, a->K, G::MT, want, r.ntk, r.ntiles, r.nsplit, r.rps);
+        if ((long)r.nsplit * a->N * a->K > a->slab_elems) return MMVAE_ERR_ARG;
+        r.M = a->M; r.N = a->N; r.K = a->K;
+        r.block0 = block; r.nblocks = ((r.nsplit + 7) / 8) * 8 * r.ntiles; block += r.nblocks;
+        r.dW = a->dw; r.ldw = a->lddw; r.db = a->db; r.slab = a->slab;
+        r.p = a->p; r.ldp = a->ldp; r.q = a->q; r.ldq = a->ldq;
+        r.pro_scale = a->pro_scale; r.pro_shift = a->pro_shift; r.pro_mask = a->pro_mask; r.ld_pro_mask = a->ld_pro_mask; r.pro_inv_keep = a->pro_inv_keep;
+        rd.slab[i] = a->slab; rd.dW[i] = a->dw; rd.nsplit[i] = r.nsplit; rd.nk[i] = a->N * a->K; rd.first[i] = elems; elems += a->N * a->K;
+    }
+    for (int i = n; i <= MMVAE_TN_GROUP_MAX; ++i) rd.first[i] = elems;
+    for (int i = n; i < MMVAE_TN_GROUP_MAX; ++i) g.pr[i].block0 = 1 << 30;
+    constexpr int LDS = 4 * G::MT * G::ROWB + 4096 + 4096;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_group_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_group_kernel<CT>), dim3(block), dim3(NTHREADS), LDS, st, g);
+    MM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((elems + 255) / 256), dim3(256), 0, st, rd);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace mm
+
+extern "C" int mmvae_gemm_tn_group(const mmvae_gemm_tn_args* args, int32_t n, void* stream) {
+    if (!args || n <= 0 || n > MMVAE_TN_GROUP_MAX) return MMVAE_ERR_ARG;
+    const long lim = 1L << 32;
+    for (int i = 0; i < n; ++i) {
+        const mmvae_gemm_tn_args* a = &args[i];
+        if (!a->p || !a->q || !a->dw || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->prec != args[0].prec) return MMVAE_ERR_ARG;
+        if ((long)a->M * a->ldp * (a->p_dtype == MMVAE_BF16 ? 2 : 4) >= lim || (long)a->M * a->ldq * (a->q_dtype == MMVAE_BF16 ? 2 : 4) >= lim) return MMVAE_ERR_ARG;
+        if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
+        for (int j = 0; j < i; ++j)            // every problem needs a slab of its own: they run side by side
+            if (args[j].slab == a->slab) return MMVAE_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (args[0].prec == MMVAE_PREC_BF16) return mm::launch_tn_group<mm::bf16>(args, n, st);
+    if (args[0].prec == MMVAE_PREC_F32) return mm::launch_tn_group<float>(args, n, st);
+    return MMVAE_ERR_ARG;
+}
 
 extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (!a || !a->p || !a->q || !a->dw) return MMVAE_ERR_ARG;

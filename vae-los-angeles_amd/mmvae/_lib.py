@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -17,6 +17,7 @@ PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY = 0, 1, 2
 EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TILE = 128
+TN_GROUP_MAX = 8        # MMVAE_TN_GROUP_MAX
 CTR_COPIES = 16384      # MMVAE_CTR_COPIES: self-advancing device counters are stored as this many identical int64 copies
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -110,6 +111,7 @@ _SIGNATURES = {
     "mmvae_prep_weights": [vp, i32, vp],
     "mmvae_gemm_nt": [C.POINTER(GemmNtArgs), vp],
     "mmvae_gemm_tn": [C.POINTER(GemmTnArgs), vp],
+    "mmvae_gemm_tn_group": [vp, i32, vp],
     "mmvae_bn_finalize": [C.POINTER(BnFinalizeArgs), vp],
     "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],

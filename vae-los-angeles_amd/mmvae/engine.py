@@ -22,6 +22,8 @@ _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
 _BN_BWD_RECOMPUTE = os.environ.get("MMVAE_BN_BWD_RECOMPUTE", "0") == "1"
 _FUSE_BN_APPLY = os.environ.get("MMVAE_FUSE_BN_APPLY", "1") == "1"       # A/B switch: BN-backward correction of first layers inside the dW GEMM
+_GROUP_TINY_DW = os.environ.get("MMVAE_GROUP_TINY_DW", "1") == "1"       # A/B switch: small-output dW GEMMs as grouped launches
+_TINY_DW_MAX = 16384                                                       # N*K at or below which a dW GEMM counts as small-output
 
 
 def set_default_precision(name):
@@ -520,13 +522,27 @@ class VAEGraph:
         slab = torch.empty(min(64 * big, 1 << 25), dtype=torch.float32, device=dev)     # <= 128 MiB; too small -> that GEMM uses atomics
         keep = []
 
-        def tn(prec_, p, q, *a, **kw):
-            ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
+        # Small-output dW GEMMs (latent / class widths: encoder heads, decoder first layers, DecoderC) are latency chains when
+        # launched alone (~25 us each for a few MB + a reduce launch): they are DEFERRED and run as one grouped launch + one
+        # reduce per flush -- after the decoders (their gradients are then final for the early all-reduce bucket) and at the end.
+        tiny = []
+
+        def tn(prec_, p, q, dw, db, N, K, q_prologue=None, p_prologue=None, tag=None):
+            if _GROUP_TINY_DW and p_prologue is None and N * K <= _TINY_DW_MAX:
+                tiny.append(dict(p=p, q=q, dw=dw, db=db, N=N, K=K, q_prologue=q_prologue))
+                return
+            ops.gemm_tn(prec_, p, q, dw, db, N, K, q_prologue=q_prologue, p_prologue=p_prologue, slab=slab, tag=tag)
+
+        def flush_tiny(tag):
+            if tiny:
+                need = ops.TN_GROUP_SPLITS * sum(t_["N"] * t_["K"] for t_ in tiny)
+                ops.gemm_tn_group(prec, tiny, torch.empty(need, dtype=torch.float32, device=dev), tag=tag)
+                tiny.clear()
         main = torch.cuda.current_stream()
         # all dW GEMMs of one backward share the slab workspace: they must stay on ONE stream (main, or the side stream)
         side = _side_stream(dev) if self.overlap_bwd else None
         if side is not None:
-            def tn(prec_, p, q, *a, **kw):
+            def tn(prec_, p, q, *a, **kw):                # (A/B form: no deferral, every dW GEMM beside the dX chain)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
@@ -544,6 +560,7 @@ class VAEGraph:
             first = False
         if not dzs:
             dzs.append(torch.zeros(B, Ld, dtype=torch.float32, device=dev))
+        flush_tiny("tiny_dW.decoders")
         if self.grad_sync is not None:
             if side is not None:                          # the decoder dW launches live on the side stream
                 ev = torch.cuda.Event()
@@ -561,6 +578,7 @@ class VAEGraph:
             self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):], train=saved["train"])
         if site is not None:
             self.enc_c.backward(d_table, grads)
+        flush_tiny("tiny_dW.heads")
         if side is not None:
             ev = torch.cuda.Event()
             ev.record(side)

@@ -236,9 +236,7 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
     return out
 
 
-def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, p_prologue=None, nsplit=0, slab=None, tag=None):
-    """dw[N,K] += pro_p(p)[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(pro_p(p)).  dw/db fp32, pre-zeroed.
-    p_prologue = (y, mean, rstd, coef): the BatchNorm-backward correction of mmvae_bn_bwd_apply applied on the load of p."""
+def _tn_args(prec, p, q, dw, db, N, K, q_prologue, p_prologue, nsplit, slab):
     _mat(p, "p"); _mat(q, "q")
     g = L.GemmTnArgs()
     g.prec, g.M, g.N, g.K = prec, p.shape[0], N, K
@@ -261,6 +259,42 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, p_prologue=None, nspli
     g.nsplit = nsplit
     if slab is not None:
         g.slab, g.slab_elems = slab.data_ptr(), slab.numel()
+    return g
+
+
+TN_GROUP_SPLITS = 256        # MMVAE_TN_GROUP_SPLITS: most batch splits a problem of a grouped launch can get (slab sizing)
+
+
+def gemm_tn_group(prec, problems, slab, tag="tiny_dW.group"):
+    """problems: list of dicts(p, q, dw, db, N, K, q_prologue=None): SMALL-output dW GEMMs (latent / class widths) launched as
+    ONE grouped GEMM + ONE reduce.  `slab`: fp32 workspace carved into one region per problem."""
+    lib = L.load()
+    for i in range(0, len(problems), L.TN_GROUP_MAX):
+        chunk = problems[i:i + L.TN_GROUP_MAX]
+        arr = (L.GemmTnArgs * len(chunk))()
+        off, nbytes = 0, 0
+        for j, pr in enumerate(chunk):
+            need = TN_GROUP_SPLITS * pr["N"] * pr["K"]
+            if off + need > slab.numel():
+                raise RuntimeError("gemm_tn_group: slab workspace too small")
+            arr[j] = _tn_args(prec, pr["p"], pr["q"], pr["dw"], pr["db"], pr["N"], pr["K"], pr.get("q_prologue"), None, 0, slab[off:off + need])
+            off += need
+            nbytes += pr["p"].shape[0] * (pr["N"] * pr["p"].element_size() + pr["K"] * pr["q"].element_size()) + 4 * pr["N"] * pr["K"]
+        with probe_span(tag if i == 0 else f"{tag}.{i}", nbytes):
+            status = lib.mmvae_gemm_tn_group(C.cast(arr, C.c_void_p), len(chunk), _stream())
+            if status == -1:
+                # a problem outside the grouped kernel's operand combinations (odd widths / alignments): the entry point checks
+                # every problem before it launches anything, so the same argument records go through the one-problem entry
+                for j in range(len(chunk)):
+                    L.check(lib.mmvae_gemm_tn(C.byref(arr[j]), _stream()), "mmvae_gemm_tn")
+            else:
+                L.check(status, "mmvae_gemm_tn_group")
+
+
+def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, p_prologue=None, nsplit=0, slab=None, tag=None):
+    """dw[N,K] += pro_p(p)[M,N]^T @ pro(q)[M,K] ; db[N] += colsum(pro_p(p)).  dw/db fp32, pre-zeroed.
+    p_prologue = (y, mean, rstd, coef): the BatchNorm-backward correction of mmvae_bn_bwd_apply applied on the load of p."""
+    g = _tn_args(prec, p, q, dw, db, N, K, q_prologue, p_prologue, nsplit, slab)
     t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_tn(C.byref(g), _stream()), "mmvae_gemm_tn")
     if t0 is not None:
