@@ -73,7 +73,11 @@ __device__ unsigned long long mm_stamps_tn[12];
 
 // One workgroup's share of a dW GEMM: output tile and batch split from its LOCAL block id L (0 .. grid of this problem), shared
 // by the one-problem kernel and the grouped kernel below.
-template <typename CT, typename PSrc, typename QSrc>
+// DMA = true (both operands plain and already in the compute type, every batch step of every split a full MT rows): the tiles
+// are moved by LDS-DMA (global_load_lds_dwordx4, 4 rows x 256 B per wave-instruction, the chunk swizzle applied to the SOURCE
+// address) instead of global -> VGPR -> ds_write; the registers -> LDS pass was what the MFMAs of this kernel waited for
+// (tools/stamp_tn.py: stage 24 % of a step + the fragment step that follows it stalled on it).
+template <typename CT, typename PSrc, typename QSrc, bool DMA = false>
 __device__ __forceinline__
 void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
              int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab,
@@ -208,7 +212,37 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
     // f32 sources hold 32 bytes per chunk in flight (two sets spill) and the BN-prologue source measured slower with two:
     // those run one register set, one step ahead
     constexpr bool TWO_SETS = sizeof(typename PSrc::Raw) + sizeof(typename QSrc::Raw) <= 32;       // plain bf16 x plain bf16 only
-    if constexpr (!TWO_SETS) {
+    if constexpr (DMA) {
+        static_assert(sizeof(CT) == 2, "the DMA form moves bf16 tiles");
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void gbl_void;
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const int prow = lane >> 4, ppos = lane & 15;
+        const int ncap = ((N + 7) & ~7) - 8, kcap = ((K + 7) & ~7) - 8;        // last whole 16-byte chunk inside a row
+        auto issue = [&](int t, int buf) {
+            unsigned char* sP = smem + buf * BUF;
+            unsigned char* sQ = sP + G::MT * G::ROWB;
+            const int m0 = m_begin + t * G::MT;                  // every step is a full MT rows (host-checked)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wv + 4 * i, r = p * 4 + prow;
+                const int ch = (((ppos >> 1) ^ G::f(r)) << 1) | (ppos & 1);      // chunk whose swizzled position is ppos
+                const unsigned rp_ = (unsigned)(m0 + r);
+                const bf16* gp = ps.p + (rp_ * (unsigned)ps.lda + (unsigned)min(n0 + ch * 8, ncap));
+                const bf16* gq = qs.p + (rp_ * (unsigned)qs.lda + (unsigned)min(k0 + ch * 8, kcap));
+                __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(sP + p * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)gq, (lds_void*)(sQ + p * 1024), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own pieces of tile t have landed
+            __syncthreads();                                     // everybody's have; nobody still reads the other buffer
+            if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+            compute(t & 1, 0);
+            compute(t & 1, 1);
+        }
+    } else if constexpr (!TWO_SETS) {
         fetch(rp0, rq0, 0);
         stage(rp0, rq0, 0, 0);
         if (nt > 1) fetch(rp0, rq0, 1);
@@ -297,13 +331,21 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
 #endif
 }
 
-template <typename CT, typename PSrc, typename QSrc>
+template <typename CT, typename PSrc, typename QSrc, bool DMA>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
                     int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
-    tn_body<CT, PSrc, QSrc>(ps, qs, dW, ldw, db, M, N, K, ntk, ntiles, nsplit, rows_per_split, slab, (int)blockIdx.x, smem);
+    tn_body<CT, PSrc, QSrc, DMA>(ps, qs, dW, ldw, db, M, N, K, ntk, ntiles, nsplit, rows_per_split, slab, (int)blockIdx.x, smem);
+}
+
+template <typename T> struct TnPlainBf16 { static constexpr bool value = false; };
+template <> struct TnPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool value = true; };
+// DMA form: plain bf16 operands and every split a whole number of full batch steps
+static inline bool tn_dma_ok(int M, int MT) {
+    static const bool off = getenv("MMVAE_NO_TN_DMA") != nullptr;           // A/B switch
+    return !off && M % MT == 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -316,7 +358,7 @@ void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* _
 //   2: P f32 (loss gradient of the class logits), Q activation type                       (DecoderC.L1)
 // ------------------------------------------------------------------------------------------
 struct TnProblem {
-    int combo, M, N, K, ntk, ntiles, nsplit, rps, block0, nblocks;
+    int combo, dma, M, N, K, ntk, ntiles, nsplit, rps, block0, nblocks;
     float* dW; long ldw; float* db; float* slab;
     const void* p; long ldp; const void* q; long ldq;
     const float* pro_scale; const float* pro_shift; const uint8_t* pro_mask; long ld_pro_mask; float pro_inv_keep;
@@ -342,6 +384,9 @@ void gemm_tn_group_kernel(const TnGroup g)
     } else if (r.combo == 1) {
         const PA ps{(const CT*)r.p, r.ldp, r.M, r.N};
         const PA qs{(const CT*)r.q, r.ldq, r.M, r.K};
+        if constexpr (sizeof(CT) == 2) {
+            if (r.dma) { tn_body<CT, PA, PA, true>(ps, qs, r.dW, r.ldw, r.db, r.M, r.N, r.K, r.ntk, r.ntiles, r.nsplit, r.rps, r.slab, L, smem); return; }
+        }
         tn_body<CT>(ps, qs, r.dW, r.ldw, r.db, r.M, r.N, r.K, r.ntk, r.ntiles, r.nsplit, r.rps, r.slab, L, smem);
     } else {
         const PF ps{(const float*)r.p, r.ldp, r.M, r.N};
@@ -438,13 +483,27 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     const int grid = ((nsplit + 7) / 8) * 8 * ntiles;
     float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
     constexpr int LDS = 4 * G::MT * G::ROWB + 4096 + 4096;
+    if constexpr (sizeof(CT) == 2 && TnPlainBf16<PSrc>::value && TnPlainBf16<QSrc>::value) {
+        if (tn_dma_ok(a->M, G::MT)) {
+            static bool attr_dma = false;
+            if (!attr_dma) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                if (e != hipSuccess) return (int)e;
+                attr_dma = true;
+            }
+            hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc, true>), dim3(grid), dim3(NTHREADS), LDS, st, ps, qs,
+                               a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
+            MM_CHECK_LAUNCH();
+            return slab ? tn_reduce(a, nsplit, st) : 0;
+        }
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc>), dim3(grid), dim3(NTHREADS), LDS, st, ps, qs,
+    hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc, false>), dim3(grid), dim3(NTHREADS), LDS, st, ps, qs,
                        a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab);
     MM_CHECK_LAUNCH();
     return slab ? tn_reduce(a, nsplit, st) : 0;
@@ -547,6 +606,7 @@ static int launch_tn_group(const mmvae_gemm_tn_args* args, int n, hipStream_t st
         tn_split(a->M, a->N, a->K, G::MT, want, r.ntk, r.ntiles, r.nsplit, r.rps);
         if ((long)r.nsplit * a->N * a->K > a->slab_elems) return MMVAE_ERR_ARG;
         r.M = a->M; r.N = a->N; r.K = a->K;
+        r.dma = (r.combo == 1 && sizeof(CT) == 2 && tn_dma_ok(a->M, G::MT)) ? 1 : 0;
         r.block0 = block; r.nblocks = ((r.nsplit + 7) / 8) * 8 * r.ntiles; block += r.nblocks;
         r.dW = a->dw; r.ldw = a->lddw; r.db = a->db; r.slab = a->slab;
         r.p = a->p; r.ldp = a->ldp; r.q = a->q; r.ldq = a->ldq;
