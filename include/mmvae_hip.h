@@ -226,10 +226,12 @@ typedef struct {
     void* g_b; int32_t g_b_dtype; int64_t ld_gb; int32_t grad_b_wrt_logit;
     float* g_c; int64_t ld_gc;
     float* g_mu; float* g_lv;
+    const float* beta_gamma_dev;      /* optional {beta, gamma} in device memory: overrides the by-value fields, so a captured hipGraph
+                                         follows the beta warm-up (optimize_hyperparameters.py:103) without re-capture */
 } mmvae_loss_args;
 int mmvae_vae_loss(const mmvae_loss_args* args, void* stream);
 /* out5 = {recon + gamma*class + beta*kld, recon, class, kld, labels out of range} (float) from sums[5]. */
-int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out5, void* stream);
+int mmvae_loss_finalize(const double* sums, float beta, float gamma, const float* beta_gamma_dev, float* out5, void* stream);
 
 /* out = g * p * (1-p): Sigmoid backward for gradients that arrive w.r.t. recon_b (decoders.py:32). */
 int mmvae_sigmoid_bwd(int32_t M, int32_t N, const float* g, int64_t ldg, const float* p, int64_t ldpp,
@@ -258,6 +260,17 @@ int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float* eps, int6
 int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /* *counter_dev += inc */
 
 /* ---------------------------------------------------------------------------------------------
+ * Minibatch assembly from a device-resident dataset: dst_t[i][:] = src_t[idx[i]][:], i < rows, for up to MMVAE_GATHER_MAX
+ * row-major tensors sharing one int64 index vector (rows / strides in BYTES, multiples of 8).  Indices outside
+ * [0, src_rows) are clamped.  Replaces: MultiModalDataset.__getitem__ + the DataLoader's default collate
+ * (src/data/dataset.py:28-39, optimize_hyperparameters.py:55-65) -- one Python call and one torch.tensor() per SAMPLE.
+ * ------------------------------------------------------------------------------------------- */
+#define MMVAE_GATHER_MAX 4
+typedef struct { const void* src; void* dst; int64_t src_row_stride; int64_t dst_row_stride; int32_t row_bytes; int32_t pad_; } mmvae_gather_item;
+int mmvae_gather_rows(const mmvae_gather_item* items_host, int32_t n_items, const int64_t* idx_dev, int32_t rows,
+                      int64_t src_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * AdamW (torch.optim.AdamW, constructed by the caller: optimize_hyperparameters.py:93-97,
  * train_dna2rna.py:185-189), all tensors in one launch per 64 tensors.  `items_host` is an array in HOST memory
  * (device pointers inside); it is copied into the kernel arguments, so nothing is uploaded and the call is graph-capturable:
@@ -266,10 +279,12 @@ int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } mmvae_adamw_item;
 int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                     uint64_t* step_dev, int32_t advance, void* stream);
+                     uint64_t* step_dev, int32_t advance, const float* lr_dev, void* stream);
 /* step_dev != NULL: bias corrections are computed in the kernel from t = *step_dev + 1 (graph-capturable) and
  * bias_corr1/2 are ignored.  advance != 0 (n_items <= 64): step_dev holds MMVAE_CTR_COPIES identical copies of the count and
- * the launch increments all of them itself (see mmvae_noise); otherwise advance the counter with mmvae_counter_add. */
+ * the launch increments all of them itself (see mmvae_noise); otherwise advance the counter with mmvae_counter_add.
+ * lr_dev != NULL: the learning rate is read from device memory (a captured graph follows ReduceLROnPlateau,
+ * train_dna2rna.py:190-195,216, without re-capture). */
 
 #ifdef __cplusplus
 }

@@ -378,6 +378,7 @@ __device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, l
 
 template <typename GT, int VA, int VD>
 __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
+    if (a.beta_gamma_dev) { a.beta = a.beta_gamma_dev[0]; a.gamma = a.beta_gamma_dev[1]; }     // hyper-parameters a captured graph can change
     const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     float n_bad = 0.f;
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
 
 // out = {total, recon, class, kld, labels out of range} as the reference returns them (losses.py:44,46); stand-alone form of the
 // tail of vae_loss_kernel (callers that keep `sums` to themselves)
-__global__ void loss_finalize_kernel(const double* sums, float beta, float gamma, float* out) {
+__global__ void loss_finalize_kernel(const double* sums, float beta, float gamma, const float* beta_gamma_dev, float* out) {
+    if (beta_gamma_dev) { beta = beta_gamma_dev[0]; gamma = beta_gamma_dev[1]; }
     const double recon = sums[0] + sums[1];
     out[0] = (float)(recon + (double)gamma * sums[2] + (double)beta * sums[3]);
     out[1] = (float)recon; out[2] = (float)sums[2]; out[3] = (float)sums[3]; out[4] = (float)sums[4];
@@ -519,13 +521,34 @@ __global__ __launch_bounds__(256) void noise_kernel(uint8_t* mask, long n_mask, 
 __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
 
 // ------------------------------------------------------------------------------------------
+// minibatch assembly: out_t[i][:] = src_t[idx[i]][:] for up to MMVAE_GATHER_MAX row-major tensors that share the index vector
+// (the RNA matrix, the DNA matrix and the site labels of one shuffled minibatch).  One wave per (tensor, row), 8-byte words.
+// ------------------------------------------------------------------------------------------
+struct GatherBatch { mmvae_gather_item it[MMVAE_GATHER_MAX]; int n; };
+__global__ __launch_bounds__(256) void gather_rows_kernel(const GatherBatch b, const int64_t* __restrict__ idx, int rows, long src_rows) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long w = wave0; w < (long)rows * b.n; w += nwaves) {
+        const int t = (int)(w / rows), i = (int)(w - (long)t * rows);
+        const mmvae_gather_item it = b.it[t];
+        long r = idx[i];
+        r = r < 0 ? 0 : (r >= src_rows ? src_rows - 1 : r);            // memory-safe on a bad index (torch would device-assert)
+        const uint2* s = (const uint2*)((const char*)it.src + r * it.src_row_stride);
+        uint2* d = (uint2*)((char*)it.dst + (long)i * it.dst_row_stride);
+        const int words = it.row_bytes >> 3;
+        for (int k = lane; k < words; k += 64) d[k] = s[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // AdamW, all tensors in one launch
 // ------------------------------------------------------------------------------------------
 struct AdamWBatch { mmvae_adamw_item items[64]; };      // passed BY VALUE (2.5 KiB of kernel arguments): no table upload,
                                                         // so the launch is hipGraph-capturable even when gradients move
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, float lr, float b1, float b2,
                                                      float eps, float wd, float bc1, float rsqrt_bc2, int maximize,
-                                                     uint64_t* step_dev, int copies) {
+                                                     uint64_t* step_dev, int copies, const float* lr_dev) {
+    if (lr_dev) lr = *lr_dev;                       // a captured graph follows the LR scheduler without re-capture
     const mmvae_adamw_item it = batch.items[blockIdx.y];
     const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;
     uint64_t steps_done = 0;
@@ -559,7 +582,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 12; }
+extern "C" int mmvae_abi_version(void) { return 13; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -688,9 +711,9 @@ extern "C" int mmvae_vae_loss(const mmvae_loss_args* a, void* stream) {
     return launch_loss<float>(a, (hipStream_t)stream);
 }
 
-extern "C" int mmvae_loss_finalize(const double* sums, float beta, float gamma, float* out4, void* stream) {
+extern "C" int mmvae_loss_finalize(const double* sums, float beta, float gamma, const float* beta_gamma_dev, float* out4, void* stream) {
     if (!sums || !out4) return MMVAE_ERR_ARG;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, beta, gamma, out4);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, beta, gamma, beta_gamma_dev, out4);
     MM_CHECK_LAUNCH();
     return 0;
 }
@@ -757,6 +780,24 @@ extern "C" int mmvae_noise(uint8_t* mask, int64_t n_mask, float keep_prob, float
     return 0;
 }
 
+extern "C" int mmvae_gather_rows(const mmvae_gather_item* items_host, int32_t n_items, const int64_t* idx_dev, int32_t rows,
+                                 int64_t src_rows, void* stream) {
+    if (!items_host || n_items <= 0 || n_items > MMVAE_GATHER_MAX || !idx_dev || rows <= 0 || src_rows <= 0) return MMVAE_ERR_ARG;
+    GatherBatch b; b.n = n_items;
+    for (int k = 0; k < n_items; ++k) {
+        const mmvae_gather_item& it = items_host[k];
+        if (!it.src || !it.dst || it.row_bytes <= 0 || it.row_bytes % 8 || it.src_row_stride % 8 || it.dst_row_stride % 8 ||
+            ((uintptr_t)it.src & 7) || ((uintptr_t)it.dst & 7)) return MMVAE_ERR_ARG;
+        b.it[k] = it;
+    }
+    const long waves = (long)rows * n_items;
+    int grid = (int)((waves + 3) / 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, b, idx_dev, rows, (long)src_rows);
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream) {
     if (!counter_dev) return MMVAE_ERR_ARG;
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, inc);
@@ -766,7 +807,7 @@ extern "C" int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stre
 
 extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_items, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int32_t maximize,
-                                uint64_t* step_dev, int32_t advance, void* stream) {
+                                uint64_t* step_dev, int32_t advance, const float* lr_dev, void* stream) {
     if (!items_host || n_items <= 0 || (!step_dev && (bias_corr1 <= 0.f || bias_corr2 <= 0.f))) return MMVAE_ERR_ARG;
     if (advance && (!step_dev || n_items > 64)) return MMVAE_ERR_ARG;       // one launch = one tick of the counter
     if (step_dev) { bias_corr1 = 1.f; bias_corr2 = 1.f; }
@@ -781,7 +822,7 @@ extern "C" int mmvae_adamw_step(const mmvae_adamw_item* items_host, int32_t n_it
         }
         const int gx = grid_for(max_numel, 256 * 4, 256);
         hipLaunchKernelGGL(adamw_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, batch, lr, beta1, beta2, eps,
-                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev, advance ? 1 : 0);
+                           weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), maximize, step_dev, advance ? 1 : 0, lr_dev);
         MM_CHECK_LAUNCH();
     }
     return 0;

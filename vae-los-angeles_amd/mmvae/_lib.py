@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -98,7 +98,11 @@ class LossArgs(C.Structure):
                 ("g_a", vp), ("g_a_dtype", i32), ("ld_ga", i64),
                 ("g_b", vp), ("g_b_dtype", i32), ("ld_gb", i64), ("grad_b_wrt_logit", i32),
                 ("g_c", vp), ("ld_gc", i64),
-                ("g_mu", vp), ("g_lv", vp)]
+                ("g_mu", vp), ("g_lv", vp), ("beta_gamma_dev", vp)]
+
+
+class GatherItem(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("src_row_stride", i64), ("dst_row_stride", i64), ("row_bytes", i32), ("pad_", i32)]
 
 
 class AdamWItem(C.Structure):
@@ -121,13 +125,14 @@ _SIGNATURES = {
     "mmvae_fuse_reparam_fwd": [C.POINTER(FuseFwdArgs), vp],
     "mmvae_fuse_reparam_bwd": [C.POINTER(FuseBwdArgs), vp],
     "mmvae_vae_loss": [C.POINTER(LossArgs), vp],
-    "mmvae_loss_finalize": [vp, f32, f32, vp, vp],
+    "mmvae_loss_finalize": [vp, f32, f32, vp, vp, vp],
+    "mmvae_gather_rows": [vp, i32, vp, i32, i64, vp],
     "mmvae_sigmoid_bwd": [i32, i32, vp, i64, vp, i64, vp, i32, i64, vp],
     "mmvae_scale_if_needed": [vp, i32, i64, vp, vp],
     "mmvae_scale_many": [C.POINTER(ScaleItem), i32, vp, vp],
     "mmvae_noise": [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, i32, vp],
     "mmvae_counter_add": [vp, C.c_uint64, vp],
-    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, i32, vp],
+    "mmvae_adamw_step": [vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, i32, vp, vp],
 }
 EXPORTED = ["mmvae_abi_version"] + sorted(_SIGNATURES)
 

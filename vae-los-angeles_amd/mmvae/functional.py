@@ -165,13 +165,14 @@ def _tag_of(t):
     return getattr(t, "_mmvae", None) if t is not None else None
 
 
-def fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
+def fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_gamma_dev=None):
     """unit_grad=True: the caller promises to call `total.backward()` with the default gradient of 1 (a captured training step
-    does): the stashed gradients are then used as they are, without the launch that multiplies them by the incoming gradient."""
+    does): the stashed gradients are then used as they are, without the launch that multiplies them by the incoming gradient.
+    beta_gamma_dev: device float32[2] overriding (beta, gamma): a captured step follows the beta warm-up without re-capture."""
     if not next(v[0] for v in terms.values() if v is not None).is_cuda:
         raise RuntimeError("the MI355X loss kernel needs CUDA/HIP tensors; there is no CPU fallback")
     with ops.pinned_stream():
-        return _fused_loss(terms, beta, gamma, class_weights, unit_grad)
+        return _fused_loss(terms, beta, gamma, class_weights, unit_grad, beta_gamma_dev)
 
 
 def _validate_loss_args(dev, B, ra, a, rb, b, lg, site, mu, lv, class_weights):
@@ -196,7 +197,7 @@ def _validate_loss_args(dev, B, ra, a, rb, b, lg, site, mu, lv, class_weights):
             raise RuntimeError(f"vae_loss: class_weights has {class_weights.numel()} entries for {lg.shape[1]} classes")
 
 
-def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
+def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_gamma_dev=None):
     """terms: dict with optional entries
          'a': (recon_a, a)  sum-MSE           'b': (recon_b, b)  sum-BCE (clamped logs)
          'c': (logits, site) weighted sum-CE  'kl': (mu, logvar)
@@ -245,8 +246,9 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         g_mu = torch.empty(B, mu.shape[1], dtype=torch.float32, device=dev) if mu is not None else None
         g_lv = torch.empty_like(g_mu) if mu is not None else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv)
-        ops.loss_finalize(sums, beta, gamma, out4)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=g_mu, g_lv=g_lv,
+                     beta_gamma_dev=beta_gamma_dev)
+        ops.loss_finalize(sums, beta, gamma, out4, beta_gamma_dev)
         stash = {"g_outs": g_outs, "g_mu": g_mu, "g_lv": g_lv, "scale": None, "unit_grad": bool(unit_grad)}
         if g_mu is None:                       # KL term absent: nothing flows into mu/logvar from this loss
             stash["g_mu"] = torch.zeros(B, saved["logvar"].shape[1], dtype=torch.float32, device=dev)
@@ -265,8 +267,9 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False):
         gm = torch.empty_like(mu_) if (need_grad and mu is not None and mu.requires_grad) else None
         gl = torch.empty_like(lv_) if (need_grad and lv is not None and lv.requires_grad) else None
         ops.vae_loss(B, recon_a=ra_, a=a_, recon_b=rb_, b=b_, logits=lg_, site=site, class_weights=cw, mu=mu_, logvar=lv_,
-                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl)
-        ops.loss_finalize(sums, beta, gamma, out4)
+                     beta=beta, gamma=gamma, sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=False, g_c=gc, g_mu=gm, g_lv=gl,
+                     beta_gamma_dev=beta_gamma_dev)
+        ops.loss_finalize(sums, beta, gamma, out4, beta_gamma_dev)
         grads = []
         for t, g in ((ra, ga), (rb, gb), (lg, gc), (mu, gm), (lv, gl)):
             if t is not None:

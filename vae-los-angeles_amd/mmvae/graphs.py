@@ -1,55 +1,107 @@
 """hipGraph capture of the whole training step (MI355X: "HIP graphs instead of a tracing compiler").
 
-One step of the reference loop (optimize_hyperparameters.py:104-113) is ~75 kernel launches; issued from
-Python they leave the GPU idle between the loss read-back and the first backward kernels.  `GraphedTrainStep`
-captures forward -> fused loss -> backward -> AdamW ONCE (through torch.cuda.CUDAGraph, i.e. hipStreamBeginCapture)
-and replays it with a single launch per step.  What makes the step capturable:
-  * no host synchronisation inside (the loss floats are read from a 16-byte device buffer AFTER the replay);
-  * the Philox noise offset and the Adam step count live on the device and are advanced by kernels;
-  * all buffers come from the graph's private pool; inputs are static tensors the caller copies batches into.
-Host scalars baked into the graph (lr, beta, gamma): call `recapture()` after changing them.
+One step of the reference loop (optimize_hyperparameters.py:104-113; train_dna2rna.py:86-96 for the directional models) is
+~60 kernel launches; issued from Python they leave the GPU idle between the loss read-back and the first backward kernels.
+`GraphedTrainStep` captures [minibatch gather ->] forward -> fused loss -> backward -> AdamW ONCE (through
+torch.cuda.CUDAGraph, i.e. hipStreamBeginCapture) and replays it with a single launch per step.  What makes the step capturable:
+  * no host synchronisation inside (the loss floats are read from a 20-byte device buffer AFTER the replay);
+  * the Philox noise offset and the Adam step count live on the device and are advanced by the kernels that read them;
+  * beta / gamma (loss) and the learning rate live in device scalars: the beta warm-up (optimize_hyperparameters.py:103) and
+    ReduceLROnPlateau (train_dna2rna.py:190-195,216) change them between replays without re-capture;
+  * all buffers come from the graph's private pool; inputs are static tensors -- either the caller copies batches into them, or
+    (`dataset=`) the step begins with mmvae_gather_rows from a device-resident dataset through a static index vector.
 
 Data parallel (`reduce=` given): the step is captured as TWO graphs -- [forward, loss, backward] and [AdamW] -- and the
 gradient all-reduce (RCCL) is issued eagerly between the two replays on the flat gradient arena.  Nothing of RCCL is
-captured, so this needs no graph support from the collective library; the price is that the all-reduce (4.3 MB at the
-default widths) no longer overlaps the encoder backward."""
+captured, so this needs no graph support from the collective library."""
 import torch
 
 from . import functional as F_
+from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, a, b, site, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None,
-                 preserve_state=False):
+    KINDS = ("multimodal", "dna2rna", "rna2dna")
+
+    def __init__(self, model, optimizer, a=None, b=None, site=None, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None,
+                 preserve_state=False, kind="multimodal", dataset=None, batch_size=None):
+        """kind: which reference loop is captured --
+             "multimodal": model(a=, b=, site=) + vae_loss                      (optimize_hyperparameters.py:106-110)
+             "dna2rna":    model(dna=b, site=) + dna2rna_loss(recon_rna, a, ..)  (train_dna2rna.py:86-92)
+             "rna2dna":    model(rna=a, site=) + rna2dna_loss(recon_dna, b, ..)  (train_rna2dna.py, same lines)
+           dataset=(A, B, SITE) device-resident full tensors + batch_size: the static batch buffers are owned here and every step
+           begins with ONE gather launch through `self.index` (int64 (batch_size,)); call `set_indices(idx)` before a step."""
+        if kind not in self.KINDS:
+            raise ValueError(f"kind must be one of {self.KINDS}")
+        self.kind = kind
+        self.dataset = dataset
+        if dataset is not None:
+            if batch_size is None:
+                raise ValueError("dataset= needs batch_size=")
+            dA, dB, dS = dataset
+            if not dA.is_cuda:
+                raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors; there is no CPU fallback")
+            dev = dA.device
+            a = torch.empty((batch_size,) + tuple(dA.shape[1:]), dtype=dA.dtype, device=dev)
+            b = torch.empty((batch_size,) + tuple(dB.shape[1:]), dtype=dB.dtype, device=dev)
+            site = torch.empty(batch_size, dtype=torch.int64, device=dev)
+            self.index = torch.arange(batch_size, dtype=torch.int64, device=dev)
         if not a.is_cuda:
             raise RuntimeError("GraphedTrainStep needs CUDA/HIP tensors; there is no CPU fallback")
         self.model, self.optimizer = model, optimizer
-        self.a, self.b, self.site = a, b, site                  # static input buffers: copy_ new batches into them
+        self.a, self.b, self.site = a, b, site                  # static input buffers: copy_ new batches into them (or set_indices)
         self.beta, self.gamma, self.class_weights = float(beta), float(gamma), class_weights
+        self.hyper = torch.tensor([self.beta, self.gamma], dtype=torch.float32, device=a.device)     # device-resident {beta, gamma}
+        self.optimizer.device_lr(True)                          # ... and learning rate: no re-capture when they change
         self.warmup = warmup
         self.reduce = reduce                                    # callable(flat_grad_arena) or None
         # preserve_state: the eager warm-up steps (they build weight / optimiser tables and allocator pools, and capture
         # cannot run without them) are UNDONE before the capture -- parameters, BatchNorm buffers, Adam moments and step
         # counts, Philox offset -- so that constructing / re-capturing the step does not advance training (resume from a
-        # checkpoint, re-capture after an LR change).  Default False: warm-up steps are ordinary training steps.
+        # checkpoint).  Default False: warm-up steps are ordinary training steps.
         self.preserve_state = preserve_state
         self.graph = self.graph_opt = None
         self._one = torch.ones((), dtype=torch.float32, device=a.device)
         self.recapture()
 
+    # --- hyper-parameters that may change between replays ---------------------------------------------------------------
+    def set_beta(self, beta, gamma=None):
+        """KL weight (and optionally gamma) of the following steps: one 8-byte host->device copy when the value changed."""
+        gamma = self.gamma if gamma is None else float(gamma)
+        if float(beta) != self.beta or gamma != self.gamma:
+            self.beta, self.gamma = float(beta), gamma
+            self.hyper.copy_(torch.tensor([self.beta, self.gamma], dtype=torch.float32), non_blocking=False)
+
+    def set_indices(self, idx):
+        """Rows of the device-resident dataset that make up the next minibatch (int64 device tensor, batch_size entries)."""
+        self.index.copy_(idx, non_blocking=True)
+
+    # --- the captured work ------------------------------------------------------------------------------------------------
+    def _forward_loss(self):
+        if self.dataset is not None:
+            dA, dB, dS = self.dataset
+            with ops.pinned_stream():
+                ops.gather_rows([(dA, self.a), (dB, self.b), (dS, self.site)], self.index, dA.shape[0])
+        if self.kind == "multimodal":
+            ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
+            terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
+        elif self.kind == "dna2rna":
+            rec, mu, lv = self.model(dna=self.b, site=self.site)
+            terms = {"a": (rec, self.a), "kl": (mu, lv)}
+        else:
+            rec, mu, lv = self.model(rna=self.a, site=self.site)
+            terms = {"b": (rec, self.b), "kl": (mu, lv)}
+        return F_.fused_loss(terms, self.beta, self.gamma, self.class_weights, unit_grad=True, beta_gamma_dev=self.hyper)
+
     def _step(self):
-        ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
-        terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
-        total, out4 = F_.fused_loss(terms, self.beta, self.gamma, self.class_weights, unit_grad=True)
+        total, out4 = self._forward_loss()
         self.optimizer.zero_grad(set_to_none=True)
         total.backward(self._one)                               # static ones: no fill launch, no gradient-scaling launch
         self.optimizer.step()
         return out4
 
     def _fwd_bwd(self):
-        ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
-        terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
-        total, out4 = F_.fused_loss(terms, self.beta, self.gamma, self.class_weights, unit_grad=True)
+        total, out4 = self._forward_loss()
         self.optimizer.zero_grad(set_to_none=True)
         total.backward(self._one)
         return out4
@@ -115,6 +167,7 @@ class GraphedTrainStep:
 
     def __call__(self):
         """Run one training step; returns the device tensor [total, recon, class, kld, labels out of range] (fp32) of that step."""
+        self.optimizer.sync_lr()                                 # a scheduler may have changed the learning rate
         self.graph.replay()
         if self.reduce is not None:
             self.reduce(self.flat)
@@ -130,7 +183,7 @@ class GraphedTrainStep:
     # `losses()` right after a replay makes the host wait for the step, and the GPU then waits for the host to wake up,
     # run Python and launch the next graph: ~55 us of idle GPU per 1.9 ms step (rocprofv3 timeline).  The reference loop
     # reads the loss only to log it (optimize_hyperparameters.py:113-117), so the read can trail the launches by one step:
-    # every replay is followed, on the same stream, by a 16-byte copy into one of two pinned host slots and an event;
+    # every replay is followed, on the same stream, by a 20-byte copy into one of two pinned host slots and an event;
     # `step_logged()` launches step i and THEN waits for the event of step i-1.  Every step's loss still reaches the host.
     def step_logged(self):
         """Launch one step; returns the (total, recon, class, kld) floats of the PREVIOUS step (None on the first call)."""
@@ -147,6 +200,11 @@ class GraphedTrainStep:
             return None
         self._pin_ev[k ^ 1].synchronize()
         return tuple(F_.read_losses(self._pin[k ^ 1]))
+
+    def reset_logged(self):
+        """Start a fresh logging pipeline (e.g. at an epoch boundary, after flush_logged())."""
+        if getattr(self, "_pin_n", 0):
+            self._pin_n = 0
 
     def flush_logged(self):
         """Losses of the last step launched by `step_logged()` (waits for it)."""

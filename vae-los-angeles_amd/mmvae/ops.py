@@ -378,8 +378,9 @@ def loss_workspace(device):
 
 def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site=None, class_weights=None,
              mu=None, logvar=None, beta=1e-3, gamma=1.0, sums=None, g_a=None, g_b=None, grad_b_wrt_logit=False,
-             g_c=None, g_mu=None, g_lv=None):
-    """sums: zeroed float64[5] (four loss sums + the count of labels outside [0, S))."""
+             g_c=None, g_mu=None, g_lv=None, beta_gamma_dev=None):
+    """sums: zeroed float64[5] (four loss sums + the count of labels outside [0, S)).  beta_gamma_dev: optional device
+    float32[2] = {beta, gamma} that overrides the by-value hyper-parameters (hipGraph replays follow the beta warm-up)."""
     x = L.LossArgs()
     x.B = B
     if recon_a is not None:
@@ -398,6 +399,7 @@ def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site
     if g_c is not None:
         x.g_c, x.ld_gc = g_c.data_ptr(), _ld(g_c)
     x.g_mu, x.g_lv = _p(g_mu), _p(g_lv)
+    x.beta_gamma_dev = _p(beta_gamma_dev)
     assert sums.dtype == torch.float64 and sums.numel() >= 5
 
     def nbytes():
@@ -412,9 +414,9 @@ def vae_loss(B, *, recon_a=None, a=None, recon_b=None, b=None, logits=None, site
         L.check(L.load().mmvae_vae_loss(C.byref(x), _stream()), "mmvae_vae_loss")
 
 
-def loss_finalize(sums, beta, gamma, out5):
+def loss_finalize(sums, beta, gamma, out5, beta_gamma_dev=None):
     assert out5.numel() >= 5
-    L.check(L.load().mmvae_loss_finalize(sums.data_ptr(), beta, gamma, out5.data_ptr(), _stream()), "mmvae_loss_finalize")
+    L.check(L.load().mmvae_loss_finalize(sums.data_ptr(), beta, gamma, _p(beta_gamma_dev), out5.data_ptr(), _stream()), "mmvae_loss_finalize")
 
 
 def sigmoid_bwd(g, p, out):
@@ -460,7 +462,27 @@ def counter_add(counter, inc):
     L.check(L.load().mmvae_counter_add(counter.data_ptr(), inc, _stream()), "mmvae_counter_add")
 
 
-def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=None):
+def gather_rows(pairs, idx, src_rows):
+    """pairs: [(src (N, ...) row-major, dst (B, ...))]: dst[i] = src[idx[i]] for every pair in ONE launch (idx: int64 (B,) on the
+    device).  The minibatch assembly of a device-resident dataset (reference: Dataset.__getitem__ + default collate per sample)."""
+    items = (L.GatherItem * len(pairs))()
+    B = idx.shape[0]
+    nbytes = 0
+    for j, (src, dst) in enumerate(pairs):
+        if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] != B or src.shape[0] != src_rows:
+            raise ValueError(f"gather_rows: pair {j}: {tuple(src.shape)} {src.dtype} -> {tuple(dst.shape)} {dst.dtype}")
+        if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("gather_rows needs contiguous device tensors")
+        row = src[0].numel() * src.element_size()
+        items[j] = L.GatherItem(src.data_ptr(), dst.data_ptr(), row, row, row, 0)
+        nbytes += 2 * B * row
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise ValueError("gather_rows: idx must be a contiguous int64 device tensor")
+    with probe_span("gather_rows", nbytes):
+        L.check(L.load().mmvae_gather_rows(C.cast(items, C.c_void_p), len(pairs), idx.data_ptr(), B, src_rows, _stream()), "mmvae_gather_rows")
+
+
+def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=None, lr_dev=None):
     """items: ctypes array of AdamWItem in host memory (device pointers inside).  step_dev: int64[CTR_COPIES] tensor of
     identical copies of the step count: bias corrections from the device counter, which the launch itself increments
     (<= 64 tensors; beyond that the copies are advanced by a fill after the launches)."""
@@ -469,6 +491,6 @@ def adamw_step(items, lr, b1, b2, eps, wd, bc1, bc2, maximize=False, step_dev=No
         assert step_dev.numel() == L.CTR_COPIES and step_dev.dtype == torch.int64
     with probe_span("adamw", lambda: 28 * sum(it.n for it in items)):
         L.check(L.load().mmvae_adamw_step(C.cast(items, C.c_void_p), len(items), lr, b1, b2, eps, wd, bc1, bc2, int(maximize),
-                                          _p(step_dev), int(tick), _stream()), "mmvae_adamw_step")
+                                          _p(step_dev), int(tick), _p(lr_dev), _stream()), "mmvae_adamw_step")
     if step_dev is not None and not tick:
         step_dev.add_(1)

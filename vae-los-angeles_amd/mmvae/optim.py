@@ -25,7 +25,32 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
+        self._lr_dev = {}             # group index -> [host value mirrored, float32[1] device]: see device_lr()
+        self.lr_on_device = False
         self._drop_caches()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # learning rate in device memory (hipGraph replays follow an LR scheduler without re-capture)
+    # ------------------------------------------------------------------------------------------------------------
+    def device_lr(self, enable=True):
+        """From now on every launch reads the learning rate from a device scalar per parameter group; `sync_lr()` copies
+        `param_groups[i]["lr"]` there when a scheduler changed it (GraphedTrainStep calls it before every replay)."""
+        self.lr_on_device = bool(enable)
+        return self
+
+    def _lr_tensor(self, gi, group, device):
+        ent = self._lr_dev.get(gi)
+        if ent is None:
+            ent = self._lr_dev[gi] = [float(group["lr"]), torch.tensor([float(group["lr"])], dtype=torch.float32, device=device)]
+        return ent
+
+    def sync_lr(self):
+        """Host -> device copy of the learning rates that changed since the last call (no-op otherwise)."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._lr_dev.get(gi)
+            if ent is not None and ent[0] != float(group["lr"]):
+                ent[0] = float(group["lr"])
+                ent[1].fill_(ent[0])
 
     # ------------------------------------------------------------------------------------------------------------
     # caches
@@ -123,7 +148,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 fast["step_t"] += 1
                 with ops.pinned_stream():
                     ops.adamw_step(fast["items"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
-                                   group["maximize"], step_dev=fast["step_dev"])
+                                   group["maximize"], step_dev=fast["step_dev"], lr_dev=self._lr_arg(gi, group, fast["params"][0].device))
                 for ent in self._step_dev.values():
                     if ent[1] is fast["step_dev"]:
                         ent[0] += 1
@@ -154,13 +179,24 @@ class FusedAdamW(torch.optim.Optimizer):
                 step_dev = self._device_step(gi if single else (gi, step_no), step_no, entries[0][0].device)
                 with ops.pinned_stream():
                     ops.adamw_step(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], 1.0, 1.0,
-                                   group["maximize"], step_dev=step_dev)
+                                   group["maximize"], step_dev=step_dev, lr_dev=self._lr_arg(gi, group, entries[0][0].device))
                 if single:
                     shared = entries[0][1]["step"]
                     for _, st in entries:
                         st["step"] = shared                       # un-aliased again by _sync_fast_steps()
                     self._fast[gi] = dict(params=[p for p, _ in entries], key=key, items=items, step_t=shared, step_dev=step_dev)
         return loss
+
+    def _lr_arg(self, gi, group, device):
+        if not self.lr_on_device:
+            return None
+        if not torch.cuda.is_current_stream_capturing():
+            ent = self._lr_tensor(gi, group, device)
+            if ent[0] != float(group["lr"]):              # eager steps keep the device value current themselves
+                ent[0] = float(group["lr"])
+                ent[1].fill_(ent[0])
+            return ent[1]
+        return self._lr_tensor(gi, group, device)[1]      # under capture the tensor must already exist (warm-up created it)
 
     @staticmethod
     def _adopt_loaded_state(p, st):
