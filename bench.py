@@ -194,12 +194,12 @@ def main():
 
     # Default on one GPU: the SAME step captured once as a hipGraph (mmvae.graphs) and replayed; the loss floats of every
     # step are still read on the host, as the reference's loop does to log them -- one step behind the launches.
-    # N > 1: two graphs, [forward, loss, backward] and [AdamW], with the RCCL all-reduce of the flat gradient arena issued
-    # eagerly between the replays (nothing of RCCL is captured).
+    # N > 1: three graphs, [forward, loss, decoder backward] | [encoder backward] | [AdamW]; the RCCL all-reduce of the decoder half
+    # of the flat gradient arena runs beside the second graph, the encoder half after it (nothing of RCCL is captured).
     graphed = None
     if not args.eager:
         from mmvae.graphs import GraphedTrainStep
-        reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if dp else None
+        reduce = (lambda flat, async_op=False: dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)) if dp else None
         try:
             graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2, reduce=reduce)
             steps_done += 2
@@ -286,10 +286,10 @@ def main():
         "config": {"workload": f"MultiModalVAE full training step (fwd + vae_loss + bwd + AdamW), RNA={A} DNA={D} sites={S} latent={L}, "
                                f"batch {B} per GPU, fp32 inputs resident in HBM, random-init weights (seed 0)",
                    "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "grad_allreduce": (None if not dp else "RCCL SUM over the flat fp32 gradient arena, between the two graph replays" if graphed is not None
+                   "grad_allreduce": (None if not dp else "RCCL SUM over the flat fp32 gradient arena: decoder half asynchronously beside the encoder-backward graph, encoder half after it" if graphed is not None
                                       else "RCCL SUM over flat fp32 arena, decoder bucket overlapped with encoder backward"),
                    "launch": ("eager (Python-issued launches)" if graphed is None else
-                              "hipGraph replay (1 launch/step)" if not dp else "2 hipGraph replays/step around the eager all-reduce"),
+                              "hipGraph replay (1 launch/step)" if not dp else "3 hipGraph replays/step ([fwd, loss, decoder bwd] | [encoder bwd] | [AdamW]) around the eager all-reduces"),
                    "loss_logging": ("every step's [total, recon, class, kld] reaches the host, as optimize_hyperparameters.py:113 reads it, but ONE STEP "
                                     "LATE (pinned 20-byte copy behind each replay; the last step's is read inside the timed region)"
                                     if (graphed is not None and os.environ.get("MMVAE_SYNC_LOSS") != "1") else "read right after each step")},

@@ -262,10 +262,14 @@ def test_graphed_step_logged_is_losses_one_step_late():
     assert all(np.isfinite(np.array(got)).ravel())
 
 
-def test_graphed_data_parallel_step_two_graphs(tmp_path):
-    """Data-parallel form of the graphed step: [forward, loss, backward] and [AdamW] captured separately, the gradient
-    all-reduce issued eagerly in between on the flat arena (one SUM all-reduce).  With a one-rank group the result
-    must equal the single-graph step; the reduce callback must see ONE contiguous fp32 tensor holding every gradient."""
+@pytest.mark.parametrize("overlap", [True, False])
+def test_graphed_data_parallel_step(tmp_path, overlap):
+    """Data-parallel forms of the graphed step (nothing of RCCL captured; SURVEY 8e: SUM all-reduce of the flat arena):
+      overlap=True : [forward, loss, decoder backward] | async all-reduce of the decoder half beside [encoder backward] | all-reduce
+                     of the encoder half | [AdamW]
+      overlap=False: [forward, loss, backward] | one all-reduce | [AdamW]
+    With a one-rank RCCL group the result must equal the single-graph step; the reduce callback must see contiguous fp32 slices
+    that together cover every gradient exactly once."""
     import torch.distributed as dist
     from mmvae.graphs import GraphedTrainStep
     A, D, S, L, B = 782, 572, 24, 20, 512
@@ -290,19 +294,28 @@ def test_graphed_data_parallel_step_two_graphs(tmp_path):
             g1(); ref.append(g1.losses()[0])
         seen = []
 
-        def reduce(flat):
-            seen.append((flat.dtype, flat.dim(), flat.numel(), flat.is_contiguous()))
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        def reduce(flat, async_op=False):
+            seen.append((flat.dtype, flat.dim(), flat.numel(), flat.is_contiguous(), flat.data_ptr(), async_op))
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
         m2, o2 = fresh()
-        g2 = GraphedTrainStep(m2, o2, a, b, site, warmup=2, reduce=reduce)
+        g2 = GraphedTrainStep(m2, o2, a, b, site, warmup=2, reduce=reduce, overlap=overlap)
+        seen.clear()                                               # warm-up calls (whole arena, eager) are not what is checked
         got = []
         for _ in range(4):
             g2(); got.append(g2.losses()[0])
     finally:
         dist.destroy_process_group()
     n_params = sum(p.numel() for p in m2.parameters())
-    assert seen and all(s == (torch.float32, 1, n_params, True) for s in seen)
+    assert seen and all(s[0] == torch.float32 and s[1] == 1 and s[3] for s in seen)
+    if overlap:
+        assert len(seen) == 8 and g2.graph_mid is not None
+        n_dec = sum(p.numel() for k, p in m2.named_parameters() if k.startswith("decoder"))
+        for tail, head in zip(seen[0::2], seen[1::2]):             # decoder half first (async, beside graph 2), then the encoder half
+            assert tail[2] == n_dec and tail[5] and head[2] == n_params - n_dec and not head[5]
+            assert tail[4] == head[4] + 4 * head[2]                # adjacent slices of ONE arena
+    else:
+        assert len(seen) == 4 and all(s[2] == n_params for s in seen)
     np.testing.assert_allclose(got, ref, rtol=2e-3)
     from model_util import CHAOTIC_BIASES
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):

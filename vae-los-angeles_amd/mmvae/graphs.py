@@ -11,9 +11,13 @@ torch.cuda.CUDAGraph, i.e. hipStreamBeginCapture) and replays it with a single l
   * all buffers come from the graph's private pool; inputs are static tensors -- either the caller copies batches into them, or
     (`dataset=`) the step begins with mmvae_gather_rows from a device-resident dataset through a static index vector.
 
-Data parallel (`reduce=` given): the step is captured as TWO graphs -- [forward, loss, backward] and [AdamW] -- and the
-gradient all-reduce (RCCL) is issued eagerly between the two replays on the flat gradient arena.  Nothing of RCCL is
-captured, so this needs no graph support from the collective library."""
+Data parallel (`reduce=` given): nothing of RCCL is captured (no graph support needed from the collective library); the
+step is cut into graphs at the points where a collective is issued eagerly on the flat gradient arena:
+  * overlap=True (default): THREE graphs -- [forward, loss, decoder backward] | [fusion + encoder backward] | [AdamW].  The cut
+    sits where engine.VAEGraph.backward calls grad_sync.early(): the decoder gradients (tail of the arena) are final there and
+    their SUM all-reduce is launched asynchronously, then graph 2 replays while RCCL runs on its own stream; the encoder half
+    is reduced after graph 2 and both are waited for before graph 3 ("overlapped with encoder backward").
+  * overlap=False: TWO graphs -- [forward, loss, backward] | [AdamW] -- with ONE all-reduce of the whole arena in between."""
 import torch
 
 from . import functional as F_
@@ -24,7 +28,7 @@ class GraphedTrainStep:
     KINDS = ("multimodal", "dna2rna", "rna2dna")
 
     def __init__(self, model, optimizer, a=None, b=None, site=None, beta=1e-3, gamma=1.0, class_weights=None, warmup=3, reduce=None,
-                 preserve_state=False, kind="multimodal", dataset=None, batch_size=None):
+                 preserve_state=False, kind="multimodal", dataset=None, batch_size=None, overlap=True):
         """kind: which reference loop is captured --
              "multimodal": model(a=, b=, site=) + vae_loss                      (optimize_hyperparameters.py:106-110)
              "dna2rna":    model(dna=b, site=) + dna2rna_loss(recon_rna, a, ..)  (train_dna2rna.py:86-92)
@@ -54,7 +58,8 @@ class GraphedTrainStep:
         self.hyper = torch.tensor([self.beta, self.gamma], dtype=torch.float32, device=a.device)     # device-resident {beta, gamma}
         self.optimizer.device_lr(True)                          # ... and learning rate: no re-capture when they change
         self.warmup = warmup
-        self.reduce = reduce                                    # callable(flat_grad_arena) or None
+        self.reduce = reduce                                    # callable(flat_grad_slice, async_op=False) -> work handle or None
+        self.overlap = bool(overlap) and reduce is not None
         # preserve_state: the eager warm-up steps (they build weight / optimiser tables and allocator pools, and capture
         # cannot run without them) are UNDONE before the capture -- parameters, BatchNorm buffers, Adam moments and step
         # counts, Philox offset -- so that constructing / re-capturing the step does not advance training (resume from a
@@ -150,12 +155,16 @@ class GraphedTrainStep:
                 F_.engine_noise().load_state_dict(snap[2], self.a.device)
                 torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            self.graph_mid = None
             if self.reduce is None:
                 with torch.cuda.graph(self.graph):
                     self.out4 = self._step()
             else:
-                with torch.cuda.graph(self.graph):
-                    self.out4 = self._fwd_bwd()
+                if self.overlap:
+                    self._capture_split(g)
+                else:
+                    with torch.cuda.graph(self.graph):
+                        self.out4 = self._fwd_bwd()
                 self.flat = self._flat_grads()                   # static address: the arena lives in the graph's private pool
                 self.graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
@@ -165,12 +174,52 @@ class GraphedTrainStep:
             g.grad_sync = sync
         return self
 
+    def _capture_split(self, g):
+        """[forward, loss, decoder backward] into self.graph and [fusion, encoder backward] into self.graph_mid: the capture is
+        ended and re-begun INSIDE backward, at the point where engine.VAEGraph.backward reports the decoder gradients final."""
+        outer = self
+
+        class _Cut:                                              # stands in for mmvae.parallel.GradAllReduce during the capture
+            def early(self_, flat, lo):
+                outer.graph.capture_end()
+                outer.cut = int(lo)
+                outer.graph_mid = torch.cuda.CUDAGraph()
+                outer.graph_mid.capture_begin(pool=outer.graph.pool(), capture_error_mode="relaxed")
+
+            def final(self_, flat):
+                pass
+
+        prev, g.grad_sync = g.grad_sync, _Cut()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream):
+                # "relaxed": the cut happens inside loss.backward(), i.e. on autograd's device thread -- only a relaxed capture may be
+                # ended from a thread other than the one that began it
+                self.graph.capture_begin(capture_error_mode="relaxed")
+                try:
+                    self.out4 = self._fwd_bwd()
+                finally:
+                    (self.graph_mid if self.graph_mid is not None else self.graph).capture_end()
+        finally:
+            g.grad_sync = prev
+        torch.cuda.current_stream().wait_stream(stream)
+        if self.graph_mid is None:
+            raise RuntimeError("the backward pass never reported its decoder gradients: nothing to overlap")
+
     def __call__(self):
         """Run one training step; returns the device tensor [total, recon, class, kld, labels out of range] (fp32) of that step."""
         self.optimizer.sync_lr()                                 # a scheduler may have changed the learning rate
         self.graph.replay()
         if self.reduce is not None:
-            self.reduce(self.flat)
+            if self.graph_mid is not None:
+                work = self.reduce(self.flat[self.cut:], async_op=True)      # decoder half: RCCL runs beside the encoder backward
+                self.graph_mid.replay()
+                self.reduce(self.flat[:self.cut])
+                if work is not None:
+                    work.wait()
+            else:
+                self.reduce(self.flat)
             self.graph_opt.replay()
         self.optimizer.note_replayed_step()
         return self.out4

@@ -159,7 +159,7 @@ def run(kind, argv=None):
         if world > 1:
             parallel.attach(model)
     else:
-        reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if world > 1 else None
+        reduce = (lambda flat, async_op=False: dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)) if world > 1 else None
         beta0 = min(1.0, start_epoch / Config.BETA_WARMUP_EPOCHS) * Config.BETA_START
         graphed = GraphedTrainStep(model, optimizer, beta=beta0, gamma=Config.GAMMA, class_weights=class_weights, warmup=1,
                                    preserve_state=True, reduce=reduce, kind=kind, dataset=tuple(tr), batch_size=B)
