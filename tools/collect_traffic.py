@@ -22,7 +22,7 @@ def per_launch(kind, tag):
     if not files:
         raise SystemExit(f"no PMC output for {kind} {tag}")
     files.sort(key=os.path.getmtime)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[-1])) if "gemm_" in r["Kernel_Name"] and "mm" in r["Kernel_Name"]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[-1])) if (("gemm_" in r["Kernel_Name"] or "vae_loss" in r["Kernel_Name"]) and "mm" in r["Kernel_Name"])
             and r["Counter_Name"] == ("FETCH_SIZE" if kind == "fetch" else "WRITE_SIZE")]
     vals = vals[2:]                      # the first launches also page the inputs in
     return sum(vals) / len(vals) * 1024.0, len(vals)

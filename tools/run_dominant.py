@@ -22,7 +22,8 @@ def bf(rows, cols):
 if tag == "DecoderB.L2.dW":            # dW[572,512] += g_b^T H2
     P, Q = bf(M, 572), bf(M, 512)
     dw, db = torch.zeros(572, 512, device=dev), torch.zeros(572, device=dev)
-    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 572, 512)
+    slab = torch.empty(1 << 24, device=dev)             # as in the engine: partial tiles of the batch splits go to a slab workspace
+    run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 572, 512, slab=slab)
 elif tag == "EncoderB.L0.dW":          # dW[512,572] += dy^T b with dy = BatchNorm-backward correction of d applied on the load (b fp32)
     P = bf(M, 512); Y = bf(M, 512); Q = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
     f = lambda: torch.rand(512, device=dev) + 0.5
@@ -54,6 +55,16 @@ elif tag in ("EncoderB.L0.dX", "EncoderB.L1.dX"):   # dX GEMM with the BatchNorm
     d = torch.empty(M, N, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, N, dtype=torch.float64, device=dev)
     run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, N, K, d, epilogue=ops.EPI_BN_BWD, h=Y[i % nbuf],
                                 bn=(sc, sh, mu, rs, mask[i % nbuf], 1.0 / 0.9), bn_phase=2, stats=st)
+elif tag == "vae_loss":                # the fused loss pass of the step: MSE(782) + BCE(572) + CE(24) + KL(20), bf16 gradients
+    ra = [torch.randn(M, 782, device=dev) for _ in range(nbuf)]; a = [torch.randn(M, 782, device=dev).abs() for _ in range(2)]
+    rb = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]; b = [torch.rand(M, 572, device=dev) for _ in range(2)]
+    rc, site = torch.randn(M, 24, device=dev), torch.randint(0, 24, (M,), device=dev)
+    mu, lv = torch.randn(M, 20, device=dev), torch.randn(M, 20, device=dev)
+    ga = torch.empty(M, 784, dtype=torch.bfloat16, device=dev); gb = torch.empty(M, 576, dtype=torch.bfloat16, device=dev)
+    gc, gm, gl = torch.empty_like(rc), torch.empty_like(mu), torch.empty_like(lv)
+    sums = torch.zeros(5, dtype=torch.float64, device=dev)
+    run = lambda i: ops.vae_loss(M, recon_a=ra[i % nbuf], a=a[i % 2], recon_b=rb[i % nbuf], b=b[i % 2], logits=rc, site=site, mu=mu, logvar=lv,
+                                 sums=sums, g_a=ga, g_b=gb, grad_b_wrt_logit=True, g_c=gc, g_mu=gm, g_lv=gl)
 else:
     raise SystemExit(f"unknown tag {tag}")
 for i in range(reps):
