@@ -37,7 +37,8 @@ enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 #define MMVAE_TILE 128          /* GEMM output tile edge */
 
 int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
-/* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernel (default 32768). */
+/* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernel (default 32768); key 1 = use of the
+ * 256x256-tile kernel gemm_nt3.h (0 off, 1 plain store epilogues, 2 every epilogue); key 2 = second-generation kernel gemm_nt2.h on/off. */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------

@@ -278,3 +278,56 @@ def test_bn_bwd_apply(prec, M, N):
     scale = float(ref.abs().max())
     tol = scale * (2.0 ** -8 if prec == PREC_BF16 else 1e-5)
     assert float((dd.float().cpu().double() - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("case", ["store_f32_sigmoid", "store_bf16_stats", "relu_mask", "bn_bwd"])
+def test_nt_kernel_generations_agree(case):
+    """The three NT kernels (gemm_nt.hip register-staged; gemm_nt2.h LDS-DMA ring, persistent; gemm_nt3.h 256 x 256 tiles) on the
+    SAME operands, switched inside one process with mmvae_set_tuning: identical products (the epilogue arithmetic is shared, the
+    MFMA accumulation order over K is the same K-step order), at a size where all of them are eligible -- ragged N (572: a
+    quarter-filled last 256-column tile, W rows clamped), K = 512, M not a multiple of 256."""
+    from mmvae import _lib as L
+    lib = L.load()
+    dev = "cuda"
+    M, N, K = 16384 + 300, (572 if case.startswith("store") else 512), (512 if case != "bn_bwd" else 256)
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev)
+    ops.WeightPrep([pl], dev).run()
+    H = torch.randn(M, ops.ceil_to(N, 8), generator=g).to(dev).bfloat16()
+    mask = (torch.rand(M, N, generator=g) > 0.1).to(torch.uint8).to(dev)
+    f = lambda: (torch.rand(N, generator=g) + 0.5).to(dev)
+    bn = (f(), f() - 1.0, f() - 1.0, f(), mask, 1.0 / 0.9)
+
+    def run():
+        stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
+        if case == "store_f32_sigmoid":
+            out = torch.empty(M, N, device=dev)
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, act=ops.ACT_SIGMOID)
+        elif case == "store_bf16_stats":
+            out = torch.zeros(M, ops.ceil_to(N, 8), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, stats=stats)
+        elif case == "relu_mask":
+            out = torch.zeros(M, ops.ceil_to(N, 8), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, epilogue=ops.EPI_RELU_MASK, h=H)
+        else:
+            out = torch.zeros(M, ops.ceil_to(N, 8), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, epilogue=ops.EPI_BN_BWD, h=H, bn=bn, bn_phase=2, stats=stats)
+        torch.cuda.synchronize()
+        return out.float(), stats
+
+    res = {}
+    try:
+        for name, nt3, nt2 in (("gen1", 0, 0), ("gen2", 0, 1), ("gen3", 2, 1)):
+            lib.mmvae_set_tuning(1, nt3); lib.mmvae_set_tuning(2, nt2)
+            res[name] = run()
+    finally:
+        lib.mmvae_set_tuning(1, 0); lib.mmvae_set_tuning(2, 1)
+    ref, ref_stats = res["gen1"]
+    for name in ("gen2", "gen3"):
+        out, stats = res[name]
+        assert torch.equal(out, ref), (name, float((out - ref).abs().max()))
+        if case in ("store_bf16_stats", "bn_bwd"):
+            assert torch.allclose(stats, ref_stats, rtol=1e-6, atol=1e-6 * float(ref_stats.abs().max())), name      # atomics order

@@ -21,6 +21,7 @@
 #include "gemm_src.h"
 #include "gemm_nt_epi.h"
 #include "gemm_nt2.h"
+#include "gemm_nt3.h"
 
 namespace mm {
 
@@ -286,6 +287,13 @@ static int launch_nt_wn(const Src& src, const void* W, long ldw, int M, int N, i
 }
 
 static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >= 256 row tiles (mmvae_set_tuning key 0)
+// kernel-generation switches (mmvae_set_tuning keys 1, 2; initial values from MMVAE_NT3 / MMVAE_NO_NT2): tests and tools flip
+// them inside one process to compare the generations on the same data
+// gemm_nt3.h is OFF by default: interleaved A/B (tools/bench_nt3.py) put the 256 x 256 tiles within +-4 % of the 128-wide kernels
+// on every hot shape (halving the L2 -> CU operand traffic bought nothing: the K loops are latency-bound, MFMA pipe busy 28 %,
+// DESIGN.md section 5) and 60 % behind on the BatchNorm-backward epilogue (scratch spills at 128 accumulators per lane)
+static int g_nt3_mode = getenv("MMVAE_NT3") ? atoi(getenv("MMVAE_NT3")) : 0;       // 0 = off, 1 = store epilogues, 2 = every epilogue
+static int g_nt2_on = getenv("MMVAE_NO_NT2") ? 0 : 1;
 
 static inline bool nt_wide_ok(int M, int N) {
     static const bool off = getenv("MMVAE_NO_WIDE_TILES") != nullptr;      // A/B switch
@@ -298,8 +306,12 @@ template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool 
 template <typename CT, typename Src, typename Epi>
 static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
     if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
+        // 256 x 256 tiles (gemm_nt3.h): wide layers with enough rows for a full round of 256-row tiles
+        const int nt3 = g_nt3_mode;
+        if (nt3 && K > 32 && N >= 256 && M >= 256 * 64 && !epi.accumulate_requested() && (Epi::NEED == 0 || nt3 >= 2))
+            return launch_nt3<Epi>(src.p, src.lda, W, ldw, M, N, K, epi, st);
         // second-generation kernel (gemm_nt2.h): operands that go into the MFMA as they are, at least two K steps
-        static const bool off = getenv("MMVAE_NO_NT2") != nullptr;      // A/B switch
+        const bool off = !g_nt2_on;
         // ... and for epilogues without operands of their own: with a saved activation / keep mask to fetch, the epilogue's loads
         // queue behind the next tile's DMA and its stores in front of the next wait (one in-order vmcnt for everything): measured
         // 5-20 % SLOWER than the first generation there, 5-10 % faster on the plain store epilogues (tools/bench_nt2.py)
@@ -403,6 +415,8 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
 
 extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     if (key == 0) { mm::g_wide_min_m = value; return 0; }
+    if (key == 1) { mm::g_nt3_mode = value; return 0; }
+    if (key == 2) { mm::g_nt2_on = value; return 0; }
     return MMVAE_ERR_ARG;
 }
 

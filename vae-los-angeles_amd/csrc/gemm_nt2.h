@@ -51,6 +51,10 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     float* red = (float*)(smem + Nt2Lds<WN>::RED);
     float* ecol = (float*)(smem + Nt2Lds<WN>::ECOL);
 
+    // diagnostic ablation bits (MMVAE_NT2_ABLATE, never set in production): 1 = issue no DMA after the first slot, 2 = no MFMA,
+    // 4 = no epilogue.  Results are wrong by construction; only the time is read (tools/bench_nt2.py).
+    const int ablate = stagger >> 24;
+    stagger &= 0xffffff;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
     const int nk = (K + BK - 1) / BK;
@@ -68,7 +72,7 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     if (T < 0) return;
     // Optional stagger (A/B knob): every other workgroup of an XCD starts late, so that co-resident workgroups -- and the chip as
     // a whole -- are not all in their store-heavy epilogues (or all in their load-heavy main loops) at the same time.
-    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {       // blocks b and b + 256 share a CU (8 XCDs x 32 CUs, round-robin)
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(32);
     }
@@ -136,18 +140,24 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt == 0) nt_epilogue_fill_cols<Epi, WN>(ecol, epi, col0, N, tid);     // previous tile's epilogue is over; visible after the next barrier
-            if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
-            else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);            // the next tile's first slot flies under this tile's epilogue
-            rd(f0a, f0b, g & 1, 0);
-            rd(f1a, f1b, g & 1, 1);
-            mma(f0a, f0b);
-            mma(f1a, f1b);
+            if (!(ablate & 1)) {
+                if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
+                else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);        // the next tile's first slot flies under this tile's epilogue
+            }
+            if (!(ablate & 2)) {
+                rd(f0a, f0b, g & 1, 0);
+                rd(f1a, f1b, g & 1, 1);
+                mma(f0a, f0b);
+                mma(f1a, f1b);
+            }
         }
         if (nk == 1) __syncthreads();                               // the column constants were written after this tile's only barrier
         // epilogue operands (saved activation, keep mask): fetched here, not a K step early as the first generation does -- 48
         // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
-        nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
-        nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+        if (!(ablate & 4)) {
+            nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
+            nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+        } else if (acc[0][0][0] == 12345.678f) epi.C[0] = from_f32<typename Epi::out_t>(acc[1][1][1] + acc[2][2][2] + acc[3][3][3]);   // keeps the MFMAs alive
         if (Tn < 0) break;
         T = Tn;
     }
@@ -169,7 +179,8 @@ static int launch_nt2(const void* A, long lda, const void* W, long ldw, int M, i
     const int per_cu = wg_env > 0 ? wg_env : (WN == 2 ? 2 : 1);
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    static const int stagger = getenv("MMVAE_NT2_STAGGER") ? atoi(getenv("MMVAE_NT2_STAGGER")) : 0;
+    static const int stagger = (getenv("MMVAE_NT2_STAGGER") ? atoi(getenv("MMVAE_NT2_STAGGER")) : 0) |
+                               ((getenv("MMVAE_NT2_ABLATE") ? atoi(getenv("MMVAE_NT2_ABLATE")) : 0) << 24);
     hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN>), dim3(grid), dim3(128 * WN), Nt2Lds<WN>::TOTAL, st,
                        (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, stagger, epi);
     MM_CHECK_LAUNCH();

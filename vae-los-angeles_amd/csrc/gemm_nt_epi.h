@@ -221,7 +221,8 @@ __device__ __forceinline__ void nt_epilogue_fill_cols(float* ecol, const Epi& ep
 // ~5000 instructions per lane (8-10 k cycles per tile, as much as 5 K steps); this one ~600.
 template <typename Epi, int ACT, bool ACCUM, bool VEC>
 __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)[4][4], const Epi& epi, const EpiOperands<Epi>& ops,
-                                                 float* red, bool want_stats, int BN, int row0, int col0, int M, int N, int lane, int wr, int wc)
+                                                 float* red, bool want_stats, int BN, int row0, int col0, int M, int N, int lane, int wr, int wc,
+                                                 int tile_rows = TILE)
 {
     typedef typename Epi::out_t OT;
     typedef typename Epi::h_t HT;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
     // rows are 128-byte aligned, lanes li and li^8 swap one half each so that every store instruction writes 8 rows x one
     // FULL line (8 lanes x 16 bytes); storing the halves from separate instructions cost +55 % HBM write traffic
     // (rocprofv3 WRITE_SIZE: 104 MB for a 67 MB output) -- the L2 wrote the partial lines back twice.
-    const bool full_lines = !ACCUM && epi.stores() && row0 + TILE <= M && col0 + BN <= n_store &&
+    const bool full_lines = !ACCUM && epi.stores() && row0 + tile_rows <= M && col0 + BN <= n_store &&
                             (epi.ldc * sizeof(OT)) % 128 == 0 && ((uintptr_t)epi.C & 127) == 0;
     const unsigned low = (li & 8) ? 0u : 0xffffffffu;           // all-ones on lanes li < 8
     const bool h_lines = VEC && Epi::NEED >= 1 && epi_h_lines(epi, col0, BN);
