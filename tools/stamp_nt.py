@@ -53,6 +53,8 @@ for wide in (1, 0):
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"N={N} K={K} M={M} {'wide 128x256' if wide else 'narrow 128x128'}: {us:.1f} us/launch (stamped build), {waves // reps} waves, {steps // waves} K steps/wave")
     names = ["reads(s1) + mma(s0) issue", "stage: vmcnt wait + ds_write + drain", "barrier wait", "fetch + reads(s0) + mma(s1) issue"]
+    if os.environ.get("NT2") == "1":          # second-generation kernel (gemm_nt2.h): plain bf16 A, K > 64
+        names = ["wait for the own DMA (vmcnt)", "barrier wait", "DMA issue of the next step", "fragment reads + 32 MFMA"]
     tot = sum(s[:4])
     for nm, v in zip(names, s[:4]):
         print(f"   {nm:40s} {v / steps:8.1f} cycles/K-step  {100.0 * v / tot:5.1f} %")

@@ -20,6 +20,9 @@
 #include "mmvae_hip.h"
 #include "gemm_src.h"
 #include "gemm_nt_epi.h"
+#ifdef MM_STAMP
+namespace mm { __device__ unsigned long long mm_stamps[12]; }
+#endif
 #include "gemm_nt2.h"
 #include "gemm_nt3.h"
 
@@ -44,7 +47,6 @@ template <int WN> struct NtLds {
 // Diagnostic build only (make STAMP=1 -> libmmvae_stamp.so, tools/stamp_nt.py): s_memtime stamps at the points of a K step
 // where the wave has drained lgkmcnt anyway, summed per wave and added to mm_stamps[] = {reads + mma0 issue, stage (vmcnt
 // wait + ds_write), barrier wait, fetch + reads + mma1 issue, K steps, waves, whole-kernel cycles summed over waves}.
-__device__ unsigned long long mm_stamps[12];
 #define MM_T(x) const unsigned long long x = __builtin_readcyclecounter()
 #define MM_ACC(i, d) st_acc[i] += (d)
 #else

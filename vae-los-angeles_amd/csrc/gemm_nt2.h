@@ -39,7 +39,7 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 template <typename Epi, int WN>
 __global__ __launch_bounds__(128 * WN, 2)
-void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, int stagger, Epi epi)
+void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
 {
     typedef bf16 CT;
     constexpr int BK = 64, BN = 64 * WN, NW = 2 * WN;
@@ -51,10 +51,6 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     float* red = (float*)(smem + Nt2Lds<WN>::RED);
     float* ecol = (float*)(smem + Nt2Lds<WN>::ECOL);
 
-    // diagnostic ablation bits (MMVAE_NT2_ABLATE, never set in production): 1 = issue no DMA after the first slot, 2 = no MFMA,
-    // 4 = no epilogue.  Results are wrong by construction; only the time is read (tools/bench_nt2.py).
-    const int ablate = stagger >> 24;
-    stagger &= 0xffffff;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
     const int nk = (K + BK - 1) / BK;
@@ -70,13 +66,6 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     int T = blockIdx.x;
     { int rt, ct; tile_rc(T, rt, ct); if (rt >= gx) T = next_tile(T); }
     if (T < 0) return;
-    // Optional stagger (A/B knob): every other workgroup of an XCD starts late, so that co-resident workgroups -- and the chip as
-    // a whole -- are not all in their store-heavy epilogues (or all in their load-heavy main loops) at the same time.
-    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {       // blocks b and b + 256 share a CU (8 XCDs x 32 CUs, round-robin)
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(32);
-    }
-
     // DMA of one ring slot: lane l of a piece writes LDS (row = 8 p + l / 8, position l % 8) and reads chunk (position ^ (row & 7))
     // of that row: the LDS image is the first generation's swz() image.
     const int prow = lane >> 3, ppos = lane & 7;
@@ -123,6 +112,15 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
             for (int n = 0; n < 4; ++n) Mma<CT>::mma(acc[m][n], bf[n], af[m]);     // swapped operands: transposed accumulator (gemm_nt_epi.h)
     };
 
+#ifdef MM_STAMP
+    // diagnostic build (make STAMP=1): cycles per K step of {wait for the own DMA, barrier, DMA issue, fragment reads + MFMA},
+    // K steps, waves, whole kernel, epilogues -- into the first generation's mm_stamps[] (tools/stamp_nt.py NT2=1)
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#define NT2_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define NT2_T(x)
+#endif
     issue(T, 0, 0);
     int g = 0;                                                      // ring position: slot = g & 1, continuous across tiles
     for (;;) {
@@ -137,30 +135,51 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // own DMA of this slot has landed (the only vector-memory operations in flight); after the barrier everybody's has,
             // and nobody still reads the other slot
+            NT2_T(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NT2_T(t1);
             __syncthreads();
+            NT2_T(t2);
             if (kt == 0) nt_epilogue_fill_cols<Epi, WN>(ecol, epi, col0, N, tid);     // previous tile's epilogue is over; visible after the next barrier
-            if (!(ablate & 1)) {
-                if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
-                else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);        // the next tile's first slot flies under this tile's epilogue
-            }
-            if (!(ablate & 2)) {
-                rd(f0a, f0b, g & 1, 0);
-                rd(f1a, f1b, g & 1, 1);
-                mma(f0a, f0b);
-                mma(f1a, f1b);
-            }
+            // DMA of the next step first, then this step's fragment reads and MFMAs.  (Interleaving the 8 DMA pieces with the 32 MFMAs
+            // -- unconditional issue in one basic block + sched_group_barrier 4 : 1 -- was measured: no gain, 5 % slower at K = 1024.)
+            if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
+            else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);            // the next tile's first slot flies under this tile's epilogue
+            NT2_T(t3);
+            rd(f0a, f0b, g & 1, 0);
+            rd(f1a, f1b, g & 1, 1);
+            mma(f0a, f0b);
+            mma(f1a, f1b);
+#ifdef MM_STAMP
+            asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[3][3][3]));      // the MFMAs of this step are issued before the stamp
+            NT2_T(t4);
+            st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += 1;
+#endif
         }
+#ifdef MM_STAMP
+        NT2_T(te0);
+#endif
         if (nk == 1) __syncthreads();                               // the column constants were written after this tile's only barrier
         // epilogue operands (saved activation, keep mask): fetched here, not a K step early as the first generation does -- 48
         // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
-        if (!(ablate & 4)) {
-            nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
-            nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
-        } else if (acc[0][0][0] == 12345.678f) epi.C[0] = from_f32<typename Epi::out_t>(acc[1][1][1] + acc[2][2][2] + acc[3][3][3]);   // keeps the MFMAs alive
+        nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
+        nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+#ifdef MM_STAMP
+        NT2_T(te1);
+        st_acc[5] += te1 - te0;
+#endif
         if (Tn < 0) break;
         T = Tn;
     }
+#ifdef MM_STAMP
+    if (tid == 0 && (blockIdx.x & 15) == 3) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        for (int i = 0; i < 5; ++i) atomicAdd(&mm_stamps[i], st_acc[i]);
+        atomicAdd(&mm_stamps[5], 1ull);
+        atomicAdd(&mm_stamps[6], t_end - t_begin);
+        atomicAdd(&mm_stamps[9], st_acc[5]);
+    }
+#endif
 }
 
 // Persistent grid: every CU gets its residency's worth of workgroups (2 of 4 waves, or 1 of 8), a multiple of 8 so that a
@@ -179,10 +198,8 @@ static int launch_nt2(const void* A, long lda, const void* W, long ldw, int M, i
     const int per_cu = wg_env > 0 ? wg_env : (WN == 2 ? 2 : 1);
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    static const int stagger = (getenv("MMVAE_NT2_STAGGER") ? atoi(getenv("MMVAE_NT2_STAGGER")) : 0) |
-                               ((getenv("MMVAE_NT2_ABLATE") ? atoi(getenv("MMVAE_NT2_ABLATE")) : 0) << 24);
     hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN>), dim3(grid), dim3(128 * WN), Nt2Lds<WN>::TOTAL, st,
-                       (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, stagger, epi);
+                       (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
     MM_CHECK_LAUNCH();
     return 0;
 }
