@@ -38,7 +38,10 @@ enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 
 int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
 /* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernel (default 32768); key 1 = use of the
- * 256x256-tile kernel gemm_nt3.h (0 off, 1 plain store epilogues, 2 every epilogue); key 2 = second-generation kernel gemm_nt2.h on/off. */
+ * 256x256-tile kernel gemm_nt3.h (0 off, 1 plain store epilogues, 2 every epilogue); key 2 = second-generation kernel gemm_nt2.h on/off;
+ * key 3 = log2 of the operand size in bytes from which row blocks are used (17..32; 0 = default 32).  mmvae_gemm_nt / mmvae_gemm_tn address their row operands with
+ * 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32 at the scaled omics widths) is processed in row blocks of
+ * at most half that threshold (2 GiB) inside the entry point; key 3 lowers it so that tests reach that path at moderate sizes. */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------

@@ -296,6 +296,8 @@ static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >
 // DESIGN.md section 5) and 60 % behind on the BatchNorm-backward epilogue (scratch spills at 128 accumulators per lane)
 static int g_nt3_mode = getenv("MMVAE_NT3") ? atoi(getenv("MMVAE_NT3")) : 0;       // 0 = off, 1 = store epilogues, 2 = every epilogue
 static int g_nt2_on = getenv("MMVAE_NO_NT2") ? 0 : 1;
+long g_block_bytes = 1L << 31;          // row-block size for operands of >= 4 GiB (mmvae_set_tuning key 3 sets log2; shared with gemm_tn.hip)
+long g_split_bytes = 1L << 32;          // operands of at least this many bytes are processed in row blocks
 
 static inline bool nt_wide_ok(int M, int N) {
     static const bool off = getenv("MMVAE_NO_WIDE_TILES") != nullptr;      // A/B switch
@@ -419,6 +421,12 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     if (key == 0) { mm::g_wide_min_m = value; return 0; }
     if (key == 1) { mm::g_nt3_mode = value; return 0; }
     if (key == 2) { mm::g_nt2_on = value; return 0; }
+    if (key == 3) {         // tests: force the row-block path at moderate sizes (value = log2 of the block bytes; 0 restores the default)
+        if (value != 0 && (value < 17 || value > 32)) return MMVAE_ERR_ARG;
+        mm::g_split_bytes = value ? 1L << value : 1L << 32;
+        mm::g_block_bytes = mm::g_split_bytes / 2;
+        return 0;
+    }
     return MMVAE_ERR_ARG;
 }
 
@@ -426,10 +434,31 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     if (!a || !a->a || !a->w || (!a->c && !(a->epilogue == MMVAE_EPI_BN_BWD && a->bn_phase == 0))) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
     if (a->ldw % 64 || ((uintptr_t)a->w & 15)) return MMVAE_ERR_ARG;
-    // the kernels address A, W and the prologue mask with 32-bit byte offsets from a scalar base
+    // The kernels address A, W and the prologue mask with 32-bit offsets from a scalar base.  Operands of 4 GiB or more (the
+    // scaled omics widths: 65 536 x 27 000 fp32 = 7 GB) are processed in row blocks -- rows are independent in this product,
+    // and the column statistics of the epilogues accumulate atomically across launches.
     const long lim = 1L << 32;
-    if ((long)a->M * a->lda * (a->a_dtype == MMVAE_BF16 ? 2 : 4) >= lim || ((long)a->N + 256) * a->ldw * 4 >= lim) return MMVAE_ERR_ARG;
-    if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
+    if (((long)a->N + 256) * a->ldw * 4 >= lim) return MMVAE_ERR_ARG;
+    const long a_row = (long)a->lda * (a->a_dtype == MMVAE_BF16 ? 2 : 4);
+    long row_bytes = a_row > (long)a->ld_pro_mask ? a_row : (long)a->ld_pro_mask;
+    if ((long)a->M * row_bytes >= mm::g_split_bytes) {
+        long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
+        if (rows >= 256) rows &= ~255L;
+        if (rows <= 0) return MMVAE_ERR_ARG;
+        for (long r0 = 0; r0 < a->M; r0 += rows) {
+            mmvae_gemm_nt_args s = *a;
+            s.M = (int32_t)((a->M - r0 < rows) ? a->M - r0 : rows);
+            s.a = (const char*)a->a + r0 * a_row;
+            if (a->c) s.c = (char*)a->c + r0 * a->ldc * (a->c_dtype == MMVAE_BF16 ? 2 : 4);
+            const long hsz = (a->prec == MMVAE_PREC_BF16) ? 2 : 4;      // H is activation-typed
+            if (a->h) s.h = (const char*)a->h + r0 * a->ldh * hsz;
+            if (a->pro_mask) s.pro_mask = a->pro_mask + r0 * a->ld_pro_mask;
+            if (a->epi_mask) s.epi_mask = a->epi_mask + r0 * a->ld_epi_mask;
+            const int rc = mmvae_gemm_nt(&s, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (a->prec == MMVAE_PREC_BF16) return mm::dispatch_src<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::dispatch_src<float>(a, st);

@@ -648,13 +648,33 @@ extern "C" int mmvae_gemm_tn_group(const mmvae_gemm_tn_args* args, int32_t n, vo
     return MMVAE_ERR_ARG;
 }
 
+namespace mm { extern long g_block_bytes, g_split_bytes; }     // gemm_nt.hip (mmvae_set_tuning key 3)
 extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (!a || !a->p || !a->q || !a->dw) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
-    // the operand sources address P, Q and the prologue mask with 32-bit byte offsets from a scalar base
-    const long lim = 1L << 32;
-    if ((long)a->M * a->ldp * (a->p_dtype == MMVAE_BF16 ? 2 : 4) >= lim || (long)a->M * a->ldq * (a->q_dtype == MMVAE_BF16 ? 2 : 4) >= lim) return MMVAE_ERR_ARG;
-    if (a->pro_mask && (long)a->M * a->ld_pro_mask >= lim) return MMVAE_ERR_ARG;
+    // The operand sources address P, Q and the prologue mask with 32-bit offsets from a scalar base.  Operands of 4 GiB or more
+    // (scaled omics widths) go through in row blocks: the batch rows are the reduction index and dW / db are accumulated.
+    const long p_row = (long)a->ldp * (a->p_dtype == MMVAE_BF16 ? 2 : 4), q_row = (long)a->ldq * (a->q_dtype == MMVAE_BF16 ? 2 : 4);
+    const long py_row = a->p_prologue ? (long)a->ld_py * (a->prec == MMVAE_PREC_BF16 ? 2 : 4) : 0;
+    long row_bytes = p_row > q_row ? p_row : q_row;
+    if (py_row > row_bytes) row_bytes = py_row;
+    if ((long)a->ld_pro_mask > row_bytes) row_bytes = a->ld_pro_mask;
+    if ((long)a->M * row_bytes >= mm::g_split_bytes) {
+        long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
+        if (rows >= 256) rows &= ~255L;
+        if (rows <= 0) return MMVAE_ERR_ARG;
+        for (long r0 = 0; r0 < a->M; r0 += rows) {
+            mmvae_gemm_tn_args s = *a;
+            s.M = (int32_t)((a->M - r0 < rows) ? a->M - r0 : rows);
+            s.p = (const char*)a->p + r0 * p_row;
+            s.q = (const char*)a->q + r0 * q_row;
+            if (a->p_y) s.p_y = (const char*)a->p_y + r0 * py_row;
+            if (a->pro_mask) s.pro_mask = a->pro_mask + r0 * a->ld_pro_mask;
+            const int rc = mmvae_gemm_tn(&s, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (a->prec == MMVAE_PREC_BF16) return mm::tn_dispatch_p<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::tn_dispatch_p<float>(a, st);
