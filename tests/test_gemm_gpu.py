@@ -331,3 +331,41 @@ def test_nt_kernel_generations_agree(case):
         assert torch.equal(out, ref), (name, float((out - ref).abs().max()))
         if case in ("store_bf16_stats", "bn_bwd"):
             assert torch.allclose(stats, ref_stats, rtol=1e-6, atol=1e-6 * float(ref_stats.abs().max())), name      # atomics order
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 512, 572), (16384, 128, 782), (8192 + 96, 384, 300), (12000, 512, 572), (16384, 100 * 8, 256)])
+def test_tn_wide_tiles(M, N, K):
+    """The wide-tile dW kernels (gemm_tn_wide.hip: 256 x 288 LDS-DMA form, 128 x 448 register form; BatchNorm-corrected bf16 P x fp32
+    Q, M >= 8192 with a slab) against float64 on the same rounded operands, against the 128 x 128 kernel (mmvae_set_tuning key 4),
+    with N / K tails, a batch that is not a multiple of the 32-row step, and a row count whose last split is short."""
+    prec = PREC_BF16
+    g = torch.Generator().manual_seed(5)
+    Np = ops.ceil_to(N, 8)
+    d = torch.zeros(M, Np, dtype=torch.bfloat16); y = torch.zeros(M, Np, dtype=torch.bfloat16)
+    d[:, :N] = torch.randn(M, N, generator=g).bfloat16(); y[:, :N] = (torch.randn(M, N, generator=g) * 2 + 0.3).bfloat16()
+    mean, rstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    coef = torch.stack([torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1]).contiguous()
+    Q = torch.randn(M, K, generator=g)
+    xh = (y[:, :N].double() - mean.double()) * rstd.double()
+    dy = coef[0].double() * (d[:, :N].double() - coef[1].double() - xh * coef[2].double())
+    dyq = _round(dy.float(), prec).double()
+    ref, refb = dyq.t() @ _round(Q, prec).double(), dyq.sum(0)
+    slab = torch.empty(1 << 25, device=DEV)
+    from mmvae import _lib
+    lib = _lib.load()
+    res = []
+    try:
+        for on in (1, 0):
+            assert lib.mmvae_set_tuning(4, on) == 0
+            dw = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV)
+            ops.gemm_tn(prec, d.to(DEV), Q.to(DEV), dw, db, N, K, p_prologue=(y.to(DEV), mean.to(DEV), rstd.to(DEV), coef.to(DEV)), slab=slab)
+            res.append((dw.cpu().double(), db.cpu().double()))
+    finally:
+        lib.mmvae_set_tuning(4, 1)
+    tol = 3e-3 * np.sqrt(M) * float(ref.abs().max())                 # a bf16 rounding of a corrected P element may flip (see above)
+    for dw, db in res:
+        assert float((dw - ref).abs().max()) <= tol
+        assert float((db - refb).abs().max()) <= 3e-3 * np.sqrt(M) * float(refb.abs().max()) + 1e-3
+    # wide vs 128 x 128: the same bf16 operands (same correction formula), only the fp32 summation order differs
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4

@@ -296,6 +296,7 @@ static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >
 // DESIGN.md section 5) and 60 % behind on the BatchNorm-backward epilogue (scratch spills at 128 accumulators per lane)
 static int g_nt3_mode = getenv("MMVAE_NT3") ? atoi(getenv("MMVAE_NT3")) : 0;       // 0 = off, 1 = store epilogues, 2 = every epilogue
 static int g_nt2_on = getenv("MMVAE_NO_NT2") ? 0 : 1;
+void tn_wide_enable(int on);             // gemm_tn_wide.hip (mmvae_set_tuning key 4)
 long g_block_bytes = 1L << 31;          // row-block size for operands of >= 4 GiB (mmvae_set_tuning key 3 sets log2; shared with gemm_tn.hip)
 long g_split_bytes = 1L << 32;          // operands of at least this many bytes are processed in row blocks
 
@@ -427,6 +428,7 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
         mm::g_block_bytes = mm::g_split_bytes / 2;
         return 0;
     }
+    if (key == 4) { mm::tn_wide_enable(value); return 0; }
     return MMVAE_ERR_ARG;
 }
 

@@ -648,7 +648,10 @@ extern "C" int mmvae_gemm_tn_group(const mmvae_gemm_tn_args* args, int32_t n, vo
     return MMVAE_ERR_ARG;
 }
 
-namespace mm { extern long g_block_bytes, g_split_bytes; }     // gemm_nt.hip (mmvae_set_tuning key 3)
+namespace mm {
+extern long g_block_bytes, g_split_bytes;                       // gemm_nt.hip (mmvae_set_tuning key 3)
+int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out);      // gemm_tn_wide.hip
+}
 extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (!a || !a->p || !a->q || !a->dw) return MMVAE_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MMVAE_ERR_ARG;
@@ -676,6 +679,11 @@ extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
         return 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    {   // the large weight gradients (first encoder layers, last decoder layer): wide tiles, gemm_tn_wide.hip
+        int ns = 0;
+        const int rc = mm::launch_tn_wide(a, st, &ns);
+        if (rc != -100) return rc ? rc : mm::tn_reduce(a, ns, st);
+    }
     if (a->prec == MMVAE_PREC_BF16) return mm::tn_dispatch_p<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::tn_dispatch_p<float>(a, st);
     return MMVAE_ERR_ARG;
