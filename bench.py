@@ -200,14 +200,10 @@ def main():
     if not args.eager:
         from mmvae.graphs import GraphedTrainStep
         reduce = (lambda flat, async_op=False: dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)) if dp else None
-        try:
-            graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2, reduce=reduce)
-            steps_done += 2
-        except Exception as exc:                                 # every rank runs the same code: all of them fall back together
-            if not dp:
-                raise
-            print(f"[bench] graphed data-parallel step unavailable ({type(exc).__name__}: {exc}); eager launches instead", file=sys.stderr)
-            graphed = None
+        # a capture failure ends the run (every rank runs the same code): no silent change of the launch form -- `--eager` is the
+        # explicit way to measure Python-issued launches
+        graphed = GraphedTrainStep(model, opt, a, b, site, beta=1e-3, gamma=1.0, warmup=2, reduce=reduce)
+        steps_done += 2
 
     def graph_step():
         # every step's loss floats reach the host, one step behind the launches (GraphedTrainStep.step_logged): the host never
