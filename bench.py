@@ -228,8 +228,12 @@ def main():
     probe = survey = None
     if not args.no_probe:
         survey = ops.PROBE = ops.KernelProbe()
+        # events need eager launches (a captured graph has no Python in it): the captured work itself, issued from Python
+        # (GraphedTrainStep.run_eager -- incl. the reconstruction losses inside the decoder GEMMs, which the public
+        # model() + vae_loss() call sequence of eager_step cannot use because it hands the reconstructions to the caller)
+        probe_step = graphed.run_eager if (graphed is not None and not dp) else eager_step
         for _ in range(3):
-            eager_step()                          # events need eager launches (a captured graph has no Python in it)
+            probe_step()
         steps_done += 3
         torch.cuda.synchronize()
         ssum = survey.summary()
@@ -263,7 +267,7 @@ def main():
     if graphed is not None and survey is not None:
         probe = ops.PROBE = ops.KernelProbe(only={dom_tag, dom_gemm})
         for _ in range(args.steps):
-            eager_step()
+            probe_step()
         torch.cuda.synchronize()
     ops.PROBE = None
     if world > 1:
@@ -330,7 +334,7 @@ def main():
                     name = k["tag"].split(".")[0]
                 elif m["kind"] == "nt":
                     name = (f"gemm_nt<{'f32' if m['a_bytes'] == 4 else 'bf16'} A{'+BN' if m.get('pro') else ''}, "
-                            f"{('store', 'relu-mask', 'bn-bwd')[m['epi']]}, {'f32' if m['c_bytes'] == 4 else 'bf16'} C, {'128x256' if m['N'] % 256 == 0 else '128x128'}>")
+                            f"{('store', 'relu-mask', 'bn-bwd', 'mse-loss', 'bce-loss')[m['epi']]}, {'f32' if m['c_bytes'] == 4 else 'bf16'} C, {'128x256' if m['N'] % 256 == 0 else '128x128'}>")
                 else:
                     name = f"gemm_tn<{'f32' if m['p_bytes'] == 4 else 'bf16'} P, {'f32' if m['q_bytes'] == 4 else 'bf16'} Q{'+BN' if m['pro_mask'] else ''}>"
                 f = fam.setdefault(name, dict(symbol=name, launches_per_step=0, ms_per_step=0.0, bytes=0.0, flops=0.0, tags=[]))

@@ -31,7 +31,7 @@ extern "C" {
 enum { MMVAE_F32 = 0, MMVAE_BF16 = 1 };                 /* storage dtype of a buffer   */
 enum { MMVAE_PREC_F32 = 0, MMVAE_PREC_BF16 = 1 };       /* MFMA operand precision      */
 enum { MMVAE_PRO_NONE = 0, MMVAE_PRO_BN_RELU_DROP = 1, MMVAE_PRO_BN_BWD_APPLY = 2 };
-enum { MMVAE_EPI_STORE = 0, MMVAE_EPI_RELU_MASK = 1, MMVAE_EPI_BN_BWD = 2 };
+enum { MMVAE_EPI_STORE = 0, MMVAE_EPI_RELU_MASK = 1, MMVAE_EPI_BN_BWD = 2, MMVAE_EPI_LOSS_MSE = 3, MMVAE_EPI_LOSS_BCE_LOGIT = 4 };
 enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 
 #define MMVAE_TILE 128          /* GEMM output tile edge */
@@ -77,6 +77,11 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
  *                                 bn_phase 1: C = coef0*(d - coef1 - xhat*coef2), coef from
  *                                 mmvae_bn_bwd_finalize.  d is recomputed from the f32 accumulators, so
  *                                 the subtraction happens before the one rounding to the activation type.
+ *            MMVAE_EPI_LOSS_MSE / MMVAE_EPI_LOSS_BCE_LOGIT: the reconstruction loss of a decoder's last layer inside its GEMM
+ *                                 (bf16 mode, bf16 A, K > 64): x = acc + bias is not stored; *stat1 (ONE f64) += sum (x - h)^2, or
+ *                                 += sum BCE(sigmoid(x), h) with the log clamp at -100 (losses.py:31,34); C (bf16, ldc % 8 == 0,
+ *                                 pad columns zeroed) = 2 (x - h), or sigmoid(x) - h = the gradient w.r.t. the logit; h = fp32 target
+ *                                 [M][ldh].  Same arithmetic as mmvae_vae_loss on the stored output; saves writing and re-reading it.
  * Replaces: nn.Linear forward = aten::addmm (encoders.py:13,18-19,31,35,40-41,54-55;
  *   decoders.py:13,15,27,29,31,44,46), relu/sigmoid (decoders.py:14,28,30,32), batch-norm
  *   statistics, and the dX mm of each Linear backward (optimize_hyperparameters.py:112).

@@ -144,3 +144,82 @@ def test_loss_rejects_mismatched_arguments():
     bad[3] = -1
     with pytest.raises(RuntimeError, match="class index"):
         vae_loss(ra, a, rb, b, rc, bad, mu, lv)
+
+
+@pytest.mark.parametrize("B", [1000, 4096])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_reconstruction_loss_inside_the_decoder_gemms(B, weighted):
+    """Training-step fusion (mmvae.graphs -> engine.VAEGraph.fused_recon): sum-MSE / sum-BCE and their gradients computed in the
+    epilogue of the decoders' last GEMMs (EPI_LOSS_MSE / EPI_LOSS_BCE_LOGIT) instead of mmvae_vae_loss on stored reconstructions
+    (losses.py:31,34).  Same arithmetic on the same fp32 values: the loss sums differ by their summation order only, the parameter
+    gradients by the order of the atomic accumulations (the bf16 gradient buffers themselves are bit-identical, next test)."""
+    import torch
+    from mmvae import engine, functional as F_
+    from src.models import MultiModalVAE
+    A, D, S, L = 782, 572, 24, 20
+    torch.manual_seed(3)
+    model = MultiModalVAE(A, D, S, L).to("cuda").set_precision("bf16").train()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = torch.randn(B, A, device="cuda", generator=g)
+    b = torch.rand(B, D, device="cuda", generator=g)
+    b[:7, :5] = 0.0; b[7:13, :5] = 1.0                                       # hard targets next to saturating logits
+    site = torch.randint(0, S, (B,), device="cuda", generator=g)
+    cw = (torch.rand(S, device="cuda", generator=g) + 0.5) if weighted else None
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def step(fuse, tb=None):
+        engine.GLOBAL_NOISE.offset_tensor(dev).zero_()
+        gr = model._graph()
+        gr.fused_recon = [a, b, None] if fuse else None
+        try:
+            ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+        finally:
+            gr.fused_recon = None
+        if fuse:
+            assert ra.stride(0) == 0 and rb.stride(0) == 0               # placeholders: the reconstructions were never stored
+        total, out5 = F_.fused_loss({"a": (ra, a), "b": (rb, b if tb is None else tb), "c": (rc, site), "kl": (mu, lv)}, 1e-3, 1.0, cw)
+        for p in model.parameters():
+            p.grad = None
+        total.backward()
+        return out5.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    o0, g0 = step(False)
+    o1, g1 = step(True)
+    np.testing.assert_allclose(o1.cpu().numpy()[:4], o0.cpu().numpy()[:4], rtol=2e-6)
+    for k in g0:            # db sums and the split dW tiles of small layers are accumulated with f32 atomics: order noise only
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * float(g0[k].abs().max()) + 1e-12, k
+    with pytest.raises(RuntimeError, match="target"):
+        step(True, tb=b.clone())
+
+
+@pytest.mark.parametrize("M,N,K,bce", [(1000, 782, 128, False), (777, 572, 512, True), (300, 333, 256, True), (4096, 128, 192, False)])
+def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
+    """mmvae_gemm_nt with MMVAE_EPI_LOSS_MSE / MMVAE_EPI_LOSS_BCE_LOGIT against the pair it replaces (store epilogue -> fp32
+    output -> mmvae_vae_loss): bit-identical bf16 gradient rows incl. zeroed pad columns, loss sum to 1e-8; target rows 16-, 8- and
+    4-byte aligned (N = 572, 782, 333), ragged row and column tiles."""
+    from mmvae.ops import PREC_BF16
+    dev = "cuda"
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device=dev).bfloat16()
+    W = torch.randn(N, K, device=dev) / K ** 0.5 * (6.0 if bce else 1.0)           # some logits saturate the sigmoid
+    bias = torch.randn(N, device=dev) * 0.1
+    pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
+    T = (torch.rand(M, N, device=dev) > 0.5).float() if bce else torch.randn(M, N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    Np = ops.ceil_to(N, 8)
+    g_ref = torch.empty(M, Np, dtype=torch.bfloat16, device=dev)
+    g_new = torch.full((M, Np), 7.0, dtype=torch.bfloat16, device=dev)
+    sums, _ = ops.loss_workspace(dev)
+    sums2 = torch.zeros(5, dtype=torch.float64, device=dev)
+    ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, act=ops.ACT_SIGMOID if bce else ops.ACT_NONE)
+    if bce:
+        ops.vae_loss(M, recon_b=out, b=T, sums=sums, g_b=g_ref, grad_b_wrt_logit=True)
+    else:
+        ops.vae_loss(M, recon_a=out, a=T, sums=sums, g_a=g_ref)
+    k = 1 if bce else 0
+    ops.gemm_nt(PREC_BF16, A, pl.w, N, K, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_BCE_LOGIT if bce else ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[k:k + 1])
+    assert torch.equal(g_ref.view(torch.int16), g_new.view(torch.int16))
+    np.testing.assert_allclose(sums2[k].item(), sums[k].item(), rtol=1e-8)
+    assert sums2[1 - k].item() == 0.0
+    with pytest.raises(RuntimeError):                                             # one K step only: not this kernel's case
+        ops.gemm_nt(PREC_BF16, A[:, :64].contiguous(), pl.w, N, 64, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[0:1])

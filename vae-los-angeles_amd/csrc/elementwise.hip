@@ -582,7 +582,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 13; }
+extern "C" int mmvae_abi_version(void) { return 14; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -686,7 +686,9 @@ static int launch_loss(const mmvae_loss_args* a, hipStream_t st) {
         if (va == 1 && a->recon_a && a->A % v == 0 && al(a->recon_a, a->ld_ra, v, 4) && al(a->a, a->ld_a, v, 4) && al(a->g_a, a->ld_ga, v, sizeof(GT))) va = v;
         if (vd == 1 && a->recon_b && a->D % v == 0 && al(a->recon_b, a->ld_rb, v, 4) && al(a->b, a->ld_b, v, 4) && al(a->g_b, a->ld_gb, v, sizeof(GT))) vd = v;
     }
-    const long work = (long)a->B * ((a->recon_a ? a->A / va : 0) + (a->recon_b ? a->D / vd : 0) + 1);
+    // vectors of the stream parts + the per-row class term + the latent elements: without the reconstruction parts (their loss runs
+    // inside the decoder GEMMs) the class / KL terms alone must still fill the chip (a row per thread, not four rows on 64 workgroups)
+    const long work = (long)a->B * ((a->recon_a ? a->A / va : 0) + (a->recon_b ? a->D / vd : 0) + (a->logits ? 4 * a->S : 0) + (a->mu ? a->L : 0) + 1);
     static const int wg_cap = getenv("MMVAE_LOSS_WG") ? atoi(getenv("MMVAE_LOSS_WG")) * 256 : 1024;
     const int grid = mm::grid_for(work, 256 * 4, wg_cap);
 #define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a)

@@ -379,6 +379,24 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
                            a->bn_phase == 1 ? nullptr : a->stat1, a->bn_phase == 1 ? nullptr : a->stat2};
         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
     }
+    case MMVAE_EPI_LOSS_MSE:
+    case MMVAE_EPI_LOSS_BCE_LOGIT: {
+        // reconstruction loss inside a decoder's last GEMM: bf16 mode, plain bf16 A, second-generation kernel, 128 x 128 tiles
+        if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
+            if (!a->h || !a->c || !a->stat1 || a->c_dtype != MMVAE_BF16 || a->accumulate || a->K <= 64) return MMVAE_ERR_ARG;
+            if (a->ldc % 8 || ((uintptr_t)a->c & 15) || ((uintptr_t)a->h & 3)) return MMVAE_ERR_ARG;
+            if ((long)a->M * a->ldh * 4 >= (1L << 40)) return MMVAE_ERR_ARG;
+            const uintptr_t hp = (uintptr_t)a->h;
+            const int vt = (a->ldh % 4 == 0 && a->N % 4 == 0 && (hp & 15) == 0) ? 4 : (a->ldh % 2 == 0 && a->N % 2 == 0 && (hp & 7) == 0) ? 2 : 1;
+            const bool mse = a->epilogue == MMVAE_EPI_LOSS_MSE;
+#define MM_LOSS_EPI(MODE, VT) { EpiLoss<MODE, VT> e{(bf16*)a->c, a->ldc, (const float*)a->h, a->ldh, a->bias, a->stat1}; \
+                                return launch_nt2<EpiLoss<MODE, VT>, 2>(src.p, src.lda, a->w, a->ldw, a->M, a->N, a->K, e, st); }
+            if (mse) { if (vt == 4) MM_LOSS_EPI(0, 4) if (vt == 2) MM_LOSS_EPI(0, 2) MM_LOSS_EPI(0, 1) }
+            if (vt == 4) MM_LOSS_EPI(1, 4) if (vt == 2) MM_LOSS_EPI(1, 2) MM_LOSS_EPI(1, 1)
+#undef MM_LOSS_EPI
+        }
+        return MMVAE_ERR_ARG;
+    }
     }
     return MMVAE_ERR_ARG;
 }

@@ -37,6 +37,78 @@ template <int WN> struct Nt2Lds {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
+// Epilogue of EpiLoss: the 128 x 128 fp32 tile goes through the ring's LDS (64 KB, free once the main loop is over: this
+// epilogue's kernel does not start the next tile's DMA early) and leaves it in a ROW-COALESCED pass: thread (row r0 + 8 i,
+// chunk c) handles 4 consecutive columns, so target loads and gradient stores are 32 lanes x 16 / 8 bytes along a row.  In
+// accumulator layout the 782- and 572-element fp32 target rows (8- / 16-byte aligned) were touched in 64-byte pieces of 16
+// different rows per instruction, which cost more than the stream kernel this replaces.  The 16-byte
+// chunks of the LDS image are XOR-ed with (row & 7): conflict-free for the accumulator writes (8 rows per lane group) and
+// for the row reads.
+template <typename Epi, int WN>
+__device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const float* ecol, float* red, f32x4 (&acc)[4][4], const Epi& epi,
+                                                  int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
+{
+    static_assert(WN == 2, "128 x 128 tiles: the fp32 tile is exactly the 64 KB ring");
+    const int li = lane & 15, lg = lane >> 4;
+    __syncthreads();                                               // every wave has finished reading the ring
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wr * 64 + m * 16 + li, ch = 16 * wc + 4 * n + lg;
+            *(f32x4*)(smem + row * 512 + ((ch ^ (row & 7)) << 4)) = acc[m][n];
+        }
+    __syncthreads();
+    const int c = tid & 31, r0 = tid >> 5;                         // 8 rows per pass, 16 passes
+    const int colg = col0 + 4 * c;
+    const int gcols = (int)min((long)((N + 7) & ~7), epi.ldg);      // gradient columns that exist (pads are written as zeros)
+    const unsigned char* src = smem + r0 * 512 + ((c ^ (r0 & 7)) << 4);     // (r0 + 8 i) & 7 == r0 & 7
+    float b4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[e] = ecol[4 * c + e];
+    const float* __restrict__ T = epi.T;
+    bf16* __restrict__ G = epi.G;
+    float lsum = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+        float t[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // 4 target vectors in flight before any is used
+            const int grow = row0 + r0 + 8 * (4 * ib + u);
+            const float* tp = T + (long)min(grow, M - 1) * epi.ldt;
+#pragma unroll
+            for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + min(colg + e, N - Epi::VT), &t[u][e]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * ib + u, grow = row0 + r0 + 8 * i;
+            const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = grow < M && colg + e < N;
+                float ge;
+                const float l = epi.term(z[e] + b4[e], t[u][e], ge);
+                lsum += ok ? l : 0.f;
+                g[e] = ok ? ge : 0.f;
+            }
+            if (grow < M && colg < gcols) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)g[e];
+                *(bf16x4*)(G + (long)grow * epi.ldg + colg) = o;
+            }
+        }
+    }
+    const float ws = wave_sum(lsum);
+    if (lane == 0) red[tid >> 6] = ws;
+    __syncthreads();                                               // also: everybody is done with the LDS tile
+    if (tid == 0) {
+        const double v = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+        if (v != 0.0) unsafeAtomicAdd(epi.sum, v);
+    }
+}
+
 template <typename Epi, int WN>
 __global__ __launch_bounds__(128 * WN, 2)
 void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
@@ -144,7 +216,7 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
             // DMA of the next step first, then this step's fragment reads and MFMAs.  (Interleaving the 8 DMA pieces with the 32 MFMAs
             // -- unconditional issue in one basic block + sched_group_barrier 4 : 1 -- was measured: no gain, 5 % slower at K = 1024.)
             if (kt + 1 < nk) issue(T, kt + 1, (g + 1) & 1);
-            else if (Tn >= 0) issue(Tn, 0, (g + 1) & 1);            // the next tile's first slot flies under this tile's epilogue
+            else if (Tn >= 0 && !Epi::LDS_STREAM) issue(Tn, 0, (g + 1) & 1);     // the next tile's first slot flies under this tile's epilogue
             NT2_T(t3);
             rd(f0a, f0b, g & 1, 0);
             rd(f1a, f1b, g & 1, 1);
@@ -162,8 +234,13 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
         if (nk == 1) __syncthreads();                               // the column constants were written after this tile's only barrier
         // epilogue operands (saved activation, keep mask): fetched here, not a K step early as the first generation does -- 48
         // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
-        nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
-        nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+        if constexpr (Epi::LDS_STREAM) {
+            nt2_loss_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+            if (Tn >= 0) issue(Tn, 0, g & 1);                       // the ring is free again (the epilogue ends in a barrier)
+        } else {
+            nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
+            nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
+        }
 #ifdef MM_STAMP
         NT2_T(te1);
         st_acc[5] += te1 - te0;

@@ -26,6 +26,7 @@ namespace mm {
 template <typename OT, bool STATS_>
 struct EpiStore {               // C = act(acc + bias) (+ C) ; stats = (sum C, sum C^2) of the ROUNDED output
     static constexpr bool STATS = STATS_;
+    static constexpr bool LDS_STREAM = false; // true: the tile leaves the kernel through an LDS image and a row-coalesced pass (EpiLoss)
     static constexpr int NEED = 0;            // operand tiles to stage: 0 none, 1 = H, 2 = H + mask
     typedef OT out_t; typedef OT h_t;
     OT* C; long ldc; const float* bias; int act; int accumulate;
@@ -55,6 +56,7 @@ struct EpiStore {               // C = act(acc + bias) (+ C) ; stats = (sum C, s
 template <typename OT, typename HT>
 struct EpiReluMask {            // dH = (H > 0) ? acc : 0
     static constexpr bool STATS = false;
+    static constexpr bool LDS_STREAM = false;
     static constexpr int NEED = 1;
     typedef OT out_t; typedef HT h_t;
     OT* C; long ldc; const HT* H; long ldh; const uint8_t* mask; long ldm;
@@ -81,6 +83,7 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
     //            the cancellation happens before the single rounding to the activation type)
     //   phase 2: C = d and the same statistics as phase 0 (one contraction; mmvae_bn_bwd_apply finishes in place)
     static constexpr bool STATS = true;
+    static constexpr bool LDS_STREAM = false;
     static constexpr int NEED = 2;
     typedef OT out_t; typedef YT h_t;
     OT* C; long ldc; const YT* H; long ldh; const uint8_t* mask; long ldm;
@@ -108,6 +111,36 @@ struct EpiBnBwd {               // BatchNorm+ReLU+Dropout backward around the dX
         const float xh = (y - cc.mu) * cc.rs;
         if (phase != 1) { if (count) { s1 += d; s2 += d * xh; } return d; }      // 0: statistics only; 2: statistics + store d
         return cc.c0 * (d - cc.c1 - xh * cc.c2);
+    }
+};
+
+// Reconstruction loss of a decoder's last layer inside its GEMM (second-generation kernel only, gemm_nt2.h): the fp32 output
+// x = acc + bias is never written.  MODE 0: sum-MSE against the fp32 target T, gradient 2 (x - T) (losses.py:31 and its
+// backward); MODE 1: p = sigmoid(x), sum-BCE with torch's log clamp at -100 against T, gradient w.r.t. the LOGIT x
+// (losses.py:34, decoders.py:32) -- the arithmetic of vae_loss_kernel (elementwise.hip) on the values the store epilogue would
+// have written.  G: bf16 gradient rows (pad columns up to the next multiple of 8 are zeroed), sum: one f64 accumulator.
+// VT: widest vector the target rows allow (4: 16-byte aligned rows and N % 4 == 0; 2: 8-byte aligned, N % 2 == 0; 1).
+template <int MODE_, int VT_>
+struct EpiLoss {
+    static constexpr bool STATS = false;
+    static constexpr bool LDS_STREAM = true;
+    static constexpr int NEED = 0;
+    static constexpr int MODE = MODE_, VT = VT_;
+    typedef float out_t; typedef float h_t;           // 4-byte output layout: a lane's accumulator (m, n)[j] is column 16 n + 4 lg + j
+    bf16* G; long ldg; const float* T; long ldt; const float* bias; double* sum;
+    struct Col { float b; };
+    static constexpr int NCOL = 1;
+    bool accumulate_requested() const { return false; }
+    __device__ __forceinline__ void fill(float* e, int BN, int cl, int c, int N) const { e[cl] = (bias && c < N) ? bias[c] : 0.f; }
+    __device__ __forceinline__ float term(float x, float t, float& g) const {
+        if constexpr (MODE == 0) { const float d = x - t; g = 2.f * d; return d * d; }
+        else {
+            const float pe = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+            const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);
+            const float pq = (1.f - pe) * pe, d = pe - t;
+            g = pq >= 1e-12f ? d : d * pq * 1e12f;
+            return -(t * lp + (1.f - t) * l1p);
+        }
     }
 };
 

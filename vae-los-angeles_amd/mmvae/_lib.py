@@ -9,12 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY = 0, 1, 2
-EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD = 0, 1, 2
+EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD, EPI_LOSS_MSE, EPI_LOSS_BCE_LOGIT = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TILE = 128
 TN_GROUP_MAX = 8        # MMVAE_TN_GROUP_MAX

@@ -321,14 +321,29 @@ class DecoderMLP:
             out += [l.weight, l.bias]
         return out
 
-    def forward(self, prec, z):
+    def can_fuse_loss(self, prec):
+        """The reconstruction loss can run inside the last layer's GEMM (EPI_LOSS_*): bf16 mode, a hidden layer in front of it
+        (bf16 A operand) and more than one K step."""
+        return prec == ops.PREC_BF16 and len(self.pl) >= 2 and self.pl[-1].K > 64
+
+    def forward(self, prec, z, fused_loss=None):
+        """fused_loss = (target fp32 [B][N], one-element float64 accumulator): the last layer does not store its output; its GEMM
+        epilogue adds the reconstruction loss (sum-MSE, or sum-BCE behind the final Sigmoid: losses.py:31,34) to the accumulator and
+        writes the bf16 gradient w.r.t. the pre-activation output.  Returns (gradient, acts) then instead of (output, acts)."""
         B, dev = z.shape[0], z.device
         adt = act_dtype(prec)
         acts = [z]
         h = z
         for j, pl in enumerate(self.pl):
             last = j == len(self.pl) - 1
-            if last:
+            if last and fused_loss is not None:
+                target, acc = fused_loss
+                if tuple(target.shape) != (B, pl.N) or target.dtype != torch.float32 or target.stride(1) != 1:
+                    raise ValueError(f"fused reconstruction loss: target must be fp32 [{B}, {pl.N}], got {tuple(target.shape)} {target.dtype}")
+                out = torch.empty(B, ceil_to(pl.N, 8), dtype=adt, device=dev)
+                ops.gemm_nt(prec, h, pl.w, pl.N, pl.K, out, bias=pl.bias, epilogue=ops.EPI_LOSS_BCE_LOGIT if self.final_sigmoid else ops.EPI_LOSS_MSE,
+                            h=target, loss_sum=acc, tag=f"{self.name}.L{j}.fwd")
+            elif last:
                 out = torch.empty(B, pl.N, dtype=torch.float32, device=dev)
                 ops.gemm_nt(prec, h, pl.w, pl.N, pl.K, out, bias=pl.bias, act=ACT_SIGMOID if self.final_sigmoid else ACT_NONE, tag=f"{self.name}.L{j}.fwd")
             else:
@@ -383,6 +398,9 @@ class VAEGraph:
         self.overlap_enc = os.environ.get("MMVAE_OVERLAP_ENC", "1") != "0" and self.overlap_dw
         self.overlap_dec = os.environ.get("MMVAE_OVERLAP_DEC", "1") != "0" and self.overlap_dw
         self.overlap_bwd = os.environ.get("MMVAE_OVERLAP_BWD", "1") != "0" and self.overlap_dw
+        # Training-step fusion (mmvae.graphs): [target or None per decoder].  The next forward then computes those decoders'
+        # reconstruction losses inside their last GEMM instead of returning the reconstruction (see DecoderMLP.forward).
+        self.fused_recon = None
 
     def param_list(self):
         out = []
@@ -476,9 +494,22 @@ class VAEGraph:
         dside = _side_stream(dev) if (self.overlap_dec and len(order) > 1) else None
         if dside is not None:
             _fork(main, dside)
+        fused = None
+        want = self.fused_recon
+        if want is not None and any(t is not None and self.decoders[i].can_fuse_loss(prec) for i, t in enumerate(want)):
+            sums, out5 = ops.loss_workspace(dev)
+            fused = saved["fused_recon"] = {"sums": sums, "out5": out5, "g": {}, "targets": {}}
         for rank_, i in enumerate(order):               # largest decoder on the main stream, the others beside it
+            dec = self.decoders[i]
+            tgt = want[i] if (fused is not None and want[i] is not None and dec.can_fuse_loss(prec)) else None
             with ops.pinned_stream(dside if (dside is not None and rank_ > 0) else main):
-                o, acts = self.decoders[i].forward(prec, z)
+                if tgt is not None:
+                    k = 1 if dec.final_sigmoid else 0                     # sums[0] = MSE, sums[1] = BCE (mmvae_vae_loss)
+                    g, acts = dec.forward(prec, z, fused_loss=(tgt, fused["sums"][k:k + 1]))
+                    fused["g"][i], fused["targets"][i] = g, tgt
+                    o = torch.empty(1, dtype=torch.float32, device=dev).expand(B, dec.out_dim)     # placeholder: no storage behind it
+                else:
+                    o, acts = dec.forward(prec, z)
             outs[i] = o
             saved["dec"][i] = (acts, o.detach())
         if dside is not None:

@@ -218,12 +218,32 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_ga
     cw = None if class_weights is None else class_weights.to(device=dev, dtype=torch.float32).contiguous()
     need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (ra, rb, lg, mu, lv))
 
+    # reconstruction terms whose loss already ran inside the decoder's last GEMM (engine.VAEGraph.fused_recon): the "reconstruction"
+    # is a placeholder, its loss sum sits in the forward's accumulators and its gradient in the forward's saved state
+    fused, fused_idx = None, {}
+    for key, (r, t) in (("a", (ra, a)), ("b", (rb, b))):
+        tg = _tag_of(r) if r is not None else None
+        fr = tg[0]["saved"].get("fused_recon") if tg is not None else None
+        if fr is not None and tg[1] == "out" and tg[2] in fr["g"]:
+            if fr["targets"][tg[2]].data_ptr() != t.data_ptr() or tuple(fr["targets"][tg[2]].shape) != tuple(t.shape):
+                raise RuntimeError("fused reconstruction loss: the target passed to the loss is not the tensor the forward was given")
+            fused, fused_idx[key] = fr, tg[2]
+    if fused is not None and not (torch.is_grad_enabled()):
+        raise RuntimeError("fused reconstruction loss needs the training step (gradients enabled)")
+    if "a" in fused_idx:
+        ra_keep, ra = ra, None
+    if "b" in fused_idx:
+        rb_keep, rb = rb, None
+
     def prep(x):
         return None if x is None else (x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous())
     ra_, a_, rb_, b_, lg_, mu_, lv_ = (prep(ra), prep(a), prep(rb), prep(b), prep(lg), prep(mu), prep(lv))
     if mu_ is not None:
         mu_, lv_ = mu_.contiguous(), lv_.contiguous()
-    sums, out4 = ops.loss_workspace(dev)                  # out4: [total, recon, class, kld, labels out of range]
+    if fused is not None:
+        sums, out4 = fused["sums"], fused["out5"]         # the decoders' GEMMs have already added their terms
+    else:
+        sums, out4 = ops.loss_workspace(dev)              # out4: [total, recon, class, kld, labels out of range]
 
     # ---- fused hand-off: all differentiable inputs are outputs of ONE forward of our model --------------------
     tags = [_tag_of(t) for t in (ra, rb, lg, mu, lv) if t is not None and t.requires_grad]
@@ -233,6 +253,8 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_ga
         adt = act_dtype(saved["prec"])
         n_dec = len(saved["dec"])
         g_outs = [None] * n_dec
+        for key, i in fused_idx.items():
+            g_outs[i] = fused["g"][i]
         ga = gb = gc = None
         if ra is not None and ra.requires_grad:
             ga = torch.empty(B, ceil_to(ra.shape[1], 8), dtype=adt, device=dev)
@@ -255,9 +277,16 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_ga
             stash["g_lv"] = torch.zeros_like(stash["g_mu"])
         saved["loss_grads"] = stash
         pads = [t for t in (ra, rb, lg, mu, lv) if t is not None]
+        if "a" in fused_idx:
+            pads.append(ra_keep)
+        if "b" in fused_idx:
+            pads.append(rb_keep)
         pads += [None] * (16 - len(pads))
         total = _LossHandleFn.apply(out4[0], stash, *pads)
         return total, out4
+
+    if fused is not None:
+        raise RuntimeError("fused reconstruction loss: the loss terms are not all outputs of the one forward that computed it")
 
     # ---- general path --------------------------------------------------------------------------------------------
     def spec(tensors):

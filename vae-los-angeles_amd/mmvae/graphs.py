@@ -18,6 +18,8 @@ step is cut into graphs at the points where a collective is issued eagerly on th
     their SUM all-reduce is launched asynchronously, then graph 2 replays while RCCL runs on its own stream; the encoder half
     is reduced after graph 2 and both are waited for before graph 3 ("overlapped with encoder backward").
   * overlap=False: TWO graphs -- [forward, loss, backward] | [AdamW] -- with ONE all-reduce of the whole arena in between."""
+import os
+
 import torch
 
 from . import functional as F_
@@ -87,16 +89,30 @@ class GraphedTrainStep:
             dA, dB, dS = self.dataset
             with ops.pinned_stream():
                 ops.gather_rows([(dA, self.a), (dB, self.b), (dS, self.site)], self.index, dA.shape[0])
-        if self.kind == "multimodal":
-            ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
-            terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
-        elif self.kind == "dna2rna":
-            rec, mu, lv = self.model(dna=self.b, site=self.site)
-            terms = {"a": (rec, self.a), "kl": (mu, lv)}
-        else:
-            rec, mu, lv = self.model(rna=self.a, site=self.site)
-            terms = {"b": (rec, self.b), "kl": (mu, lv)}
+        # The step never looks at the reconstructions themselves: their loss terms and gradients are computed inside the decoders'
+        # last GEMMs (engine.VAEGraph.fused_recon) instead of writing them as fp32 and reading them back with their targets.
+        g = self.model._graph()
+        fuse = os.environ.get("MMVAE_NO_LOSS_EPILOGUE") is None
+        try:
+            if self.kind == "multimodal":
+                g.fused_recon = [self.a, self.b, None] if fuse else None
+                ra, rb, rc, mu, lv = self.model(a=self.a, b=self.b, site=self.site)
+                terms = {"a": (ra, self.a), "b": (rb, self.b), "c": (rc, self.site), "kl": (mu, lv)}
+            elif self.kind == "dna2rna":
+                g.fused_recon = [self.a] if fuse else None
+                rec, mu, lv = self.model(dna=self.b, site=self.site)
+                terms = {"a": (rec, self.a), "kl": (mu, lv)}
+            else:
+                g.fused_recon = [self.b] if fuse else None
+                rec, mu, lv = self.model(rna=self.a, site=self.site)
+                terms = {"b": (rec, self.b), "kl": (mu, lv)}
+        finally:
+            g.fused_recon = None
         return F_.fused_loss(terms, self.beta, self.gamma, self.class_weights, unit_grad=True, beta_gamma_dev=self.hyper)
+
+    def run_eager(self):
+        """One training step of exactly the captured work, issued from Python (profiling passes: events need eager launches)."""
+        return self._step()
 
     def _step(self):
         total, out4 = self._forward_loss()

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (F32, BF16, PREC_F32, PREC_BF16, PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY, EPI_STORE, EPI_RELU_MASK,
-                   EPI_BN_BWD, ACT_NONE, ACT_RELU, ACT_SIGMOID, TILE)
+                   EPI_BN_BWD, EPI_LOSS_MSE, EPI_LOSS_BCE_LOGIT, ACT_NONE, ACT_RELU, ACT_SIGMOID, TILE)
 
 DROP_P = 0.1                      # nn.Dropout(0.1), reference src/models/encoders.py:16,34,38
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # nn.BatchNorm1d defaults, encoders.py:14,32,36
@@ -194,10 +194,11 @@ class WeightPrep:
 # GEMMs
 # --------------------------------------------------------------------------------------------
 def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
-            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, tag=None):
+            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, loss_sum=None, tag=None):
     """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
     bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD (out=None, stats given:
-    statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator."""
+    statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator.
+    EPI_LOSS_MSE / EPI_LOSS_BCE_LOGIT: h = fp32 target, out = bf16 gradient, loss_sum = one-element float64 view that is added to."""
     _mat(a, "a"); _mat(w_lp, "w")
     if out is not None:
         _mat(out, "out")
@@ -227,10 +228,14 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.shape[0] == 2 and stats.shape[1] >= N and stats.stride(1) == 1
         g.stat1, g.stat2 = stats[0].data_ptr(), stats[1].data_ptr()
+    if loss_sum is not None:
+        assert loss_sum.dtype == torch.float64 and h is not None and h.dtype == torch.float32
+        g.stat1 = loss_sum.data_ptr()
     t0 = PROBE.begin() if (PROBE is not None and PROBE.wants(tag)) else None
     L.check(L.load().mmvae_gemm_nt(C.byref(g), _stream()), "mmvae_gemm_nt")
     if t0 is not None:
-        PROBE.end(tag, t0, dict(kind="nt", M=M, N=N, K=K, a_bytes=a.element_size(), c_bytes=0 if out is None else out.element_size(),
+        PROBE.end(tag, t0, dict(kind="nt", M=M, N=N, K=K, a_bytes=a.element_size(),
+                                c_bytes=0 if out is None else out.element_size() + (4 if loss_sum is not None else 0),
                                 pro=prologue is not None, pro_mask=prologue is not None and prologue[2] is not None,
                                 epi=epilogue, epi_mask=bn is not None and bn[4] is not None, act_bytes=2 if prec == PREC_BF16 else 4))
     return out
