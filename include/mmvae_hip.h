@@ -42,7 +42,8 @@ int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes bindi
  * key 3 = log2 of the operand size in bytes from which row blocks are used (17..32; 0 = default 32).  mmvae_gemm_nt / mmvae_gemm_tn address their row operands with
  * 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32 at the scaled omics widths) is processed in row blocks of
  * at most half that threshold (2 GiB) inside the entry point; key 3 lowers it so that tests reach that path at moderate sizes;
- * key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off. */
+ * key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off; key 5 = LDS-DMA form of the NT kernel for fp32 A
+ * operands (gemm_nt2.h) on/off (default off: measured equal). */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------

@@ -305,6 +305,11 @@ static inline bool nt_wide_ok(int M, int N) {
     return !off && N % 256 == 0 && M >= g_wide_min_m;       // the prepared W has ceil128(N) rows: whole 256-column tiles only
 }
 
+template <typename T> struct IsPlainF32x4 { static constexpr bool value = false; };
+template <> struct IsPlainF32x4<SrcPlain<bf16, float, 4>> { static constexpr bool value = true; };
+// measured equal to the register staging on EncoderB.L0.fwd (96 vs 97-101 us, tools/bench_ntf32.py; the layer is bound by the 64 KB
+// of A + W a CU ingests per K step either way): off by default, kept as the A/B arm (mmvae_set_tuning key 5, MMVAE_NT2_F32=1)
+static int g_nt2_f32 = getenv("MMVAE_NT2_F32") ? 1 : 0;
 template <typename T> struct IsPlainBf16 { static constexpr bool value = false; };
 template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool value = true; };
 
@@ -325,6 +330,11 @@ static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int 
             if (!narrow && nt_wide_ok(M, N)) return launch_nt2<Epi, 4>(src.p, src.lda, W, ldw, M, N, K, epi, st);
             return launch_nt2<Epi, 2>(src.p, src.lda, W, ldw, M, N, K, epi, st);
         }
+    }
+    if constexpr (sizeof(CT) == 2 && IsPlainF32x4<Src>::value && Epi::NEED == 0) {
+        // fp32 A with 16-byte aligned rows (EncoderB.L0: the caller's input batch): the raw tile by LDS-DMA, converted at fragment time
+        // (gemm_nt2.h, AT = float); 128 x 256 tiles only -- a 128-column tile's ring would leave one 4-wave workgroup per CU
+        if (g_nt2_f32 && K > 64 && !epi.accumulate_requested() && nt_wide_ok(M, N)) return launch_nt2<Epi, 4, float>(src.p, src.lda, W, ldw, M, N, K, epi, st);
     }
     if constexpr (sizeof(CT) == 2) {
         if (nt_wide_ok(M, N) && !epi.accumulate_requested()) return launch_nt_wn<CT, Src, Epi, 4>(src, W, ldw, M, N, K, epi, st);
@@ -447,6 +457,7 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
         return 0;
     }
     if (key == 4) { mm::tn_wide_enable(value); return 0; }
+    if (key == 5) { mm::g_nt2_f32 = value; return 0; }
     return MMVAE_ERR_ARG;
 }
 

@@ -24,8 +24,11 @@
 
 namespace mm {
 
-template <int WN> struct Nt2Lds {
-    static constexpr int A_BYTES = TILE * ROW_BYTES;               // 16 KiB
+// AT = float (fp32 A: the first encoder layers read the caller's input batch): the RAW fp32 tile goes through the DMA -- a K step of 64
+// elements is two [128][128 B] images (k 0..31, 32..63) with the same swizzle -- and is converted on the way from LDS to the MFMA
+// (two ds_read_b128 + four v_cvt_pk_bf16_f32 per fragment).  The first generation moves that operand global -> VGPR -> convert -> LDS.
+template <int WN, int ASZ = 2> struct Nt2Lds {
+    static constexpr int A_BYTES = TILE * ROW_BYTES * (ASZ / 2);   // 16 KiB (bf16) / 32 KiB (fp32)
     static constexpr int W_BYTES = 64 * WN * ROW_BYTES;            // 8 KiB * WN
     static constexpr int SLOT = A_BYTES + W_BYTES;
     static constexpr int RING = 2 * SLOT;
@@ -50,6 +53,20 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
 {
     static_assert(WN == 2, "128 x 128 tiles: the fp32 tile is exactly the 64 KB ring");
     const int li = lane & 15, lg = lane >> 4;
+    const int c = tid & 31, r0 = tid >> 5;                         // row-coalesced pass: 8 rows per pass, 16 passes, 4 columns per thread
+    const int colg = col0 + 4 * c;
+    const float* __restrict__ T = epi.T;
+    bf16* __restrict__ G = epi.G;
+    // ALL 16 target vectors of the thread are requested first (64 registers -- the accumulators die in the LDS image below): with 4
+    // in flight per thread the pass ran at the latency-bound 3.6 TB/s of 32 KB in flight per CU; the LDS transposition now covers
+    // their trip.  Branch-free clamped addresses (rows past M, columns past N are masked when used).
+    float t[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float* tp = T + (long)min(row0 + r0 + 8 * i, M - 1) * epi.ldt;
+#pragma unroll
+        for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + min(colg + e, N - Epi::VT), &t[i][e]);
+    }
     __syncthreads();                                               // every wave has finished reading the ring
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -59,45 +76,30 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
             *(f32x4*)(smem + row * 512 + ((ch ^ (row & 7)) << 4)) = acc[m][n];
         }
     __syncthreads();
-    const int c = tid & 31, r0 = tid >> 5;                         // 8 rows per pass, 16 passes
-    const int colg = col0 + 4 * c;
     const int gcols = (int)min((long)((N + 7) & ~7), epi.ldg);      // gradient columns that exist (pads are written as zeros)
     const unsigned char* src = smem + r0 * 512 + ((c ^ (r0 & 7)) << 4);     // (r0 + 8 i) & 7 == r0 & 7
     float b4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) b4[e] = ecol[4 * c + e];
-    const float* __restrict__ T = epi.T;
-    bf16* __restrict__ G = epi.G;
     float lsum = 0.f;
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-        float t[4][4];
+    for (int i = 0; i < 16; ++i) {
+        const int grow = row0 + r0 + 8 * i;
+        const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+        float g[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                              // 4 target vectors in flight before any is used
-            const int grow = row0 + r0 + 8 * (4 * ib + u);
-            const float* tp = T + (long)min(grow, M - 1) * epi.ldt;
-#pragma unroll
-            for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + min(colg + e, N - Epi::VT), &t[u][e]);
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = grow < M && colg + e < N;
+            float ge;
+            const float l = epi.term(z[e] + b4[e], t[i][e], ge);
+            lsum += ok ? l : 0.f;
+            g[e] = ok ? ge : 0.f;
         }
+        if (grow < M && colg < gcols) {
+            bf16x4 o;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * ib + u, grow = row0 + r0 + 8 * i;
-            const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
-            float g[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = grow < M && colg + e < N;
-                float ge;
-                const float l = epi.term(z[e] + b4[e], t[u][e], ge);
-                lsum += ok ? l : 0.f;
-                g[e] = ok ? ge : 0.f;
-            }
-            if (grow < M && colg < gcols) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)g[e];
-                *(bf16x4*)(G + (long)grow * epi.ldg + colg) = o;
-            }
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)g[e];
+            *(bf16x4*)(G + (long)grow * epi.ldg + colg) = o;
         }
     }
     const float ws = wave_sum(lsum);
@@ -109,24 +111,26 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
     }
 }
 
-template <typename Epi, int WN>
+template <typename Epi, int WN, typename AT = bf16>
 __global__ __launch_bounds__(128 * WN, 2)
-void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
+void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
 {
     typedef bf16 CT;
+    constexpr bool AF = sizeof(AT) == 4;
+    typedef Nt2Lds<WN, (int)sizeof(AT)> LD;
     constexpr int BK = 64, BN = 64 * WN, NW = 2 * WN;
-    constexpr int A_PIECES = TILE / 8, W_PIECES = BN / 8;          // 1 KiB pieces (8 rows x 128 B) per slot
+    constexpr int A_PIECES = (TILE / 8) * (AF ? 2 : 1), W_PIECES = BN / 8;      // 1 KiB pieces (8 rows x 128 B) per slot
     constexpr int A_PER = A_PIECES / NW, W_PER = W_PIECES / NW;
     typedef Mma<CT>::frag frag;
     typedef EpiCols<sizeof(typename Epi::out_t) == 2> EC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = (float*)(smem + Nt2Lds<WN>::RED);
-    float* ecol = (float*)(smem + Nt2Lds<WN>::ECOL);
+    float* red = (float*)(smem + LD::RED);
+    float* ecol = (float*)(smem + LD::ECOL);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
     const int nk = (K + BK - 1) / BK;
-    const int kmax = ((K + 7) & ~7) - 8;                           // last 16-byte chunk that lies inside an A row (rows are padded to 8)
+    const int kmax = AF ? K - 4 : ((K + 7) & ~7) - 8;              // last 16-byte chunk that lies inside an A row (bf16 rows are padded to 8; fp32: K % 4 == 0)
     const int ntiles = ((gx + 7) / 8) * 8 * gy;                    // tile ids incl. the padding of gx to a multiple of 8
 
     // tile id T -> (row tile, column tile): ids that differ by 8 run on one XCD; the column tiles of a row tile are adjacent there
@@ -144,15 +148,16 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     auto issue = [&](int tile, int kt, int slot) {
         int rt, ct; tile_rc(tile, rt, ct);
         const int row0 = rt * TILE, col0 = ct * BN;
-        unsigned char* sA = smem + slot * Nt2Lds<WN>::SLOT;
-        unsigned char* sW = sA + Nt2Lds<WN>::A_BYTES;
-        const bf16* Ak = A + kt * BK;                               // wave-uniform part of the address
+        unsigned char* sA = smem + slot * LD::SLOT;
+        unsigned char* sW = sA + LD::A_BYTES;
+        const AT* Ak = A + kt * BK;                                 // wave-uniform part of the address
         const bf16* Wk = W + kt * BK;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int p = wid + NW * i, r = p * 8 + prow;
+            const int p = wid + NW * i;
+            const int r = (AF ? (p & 15) : p) * 8 + prow;           // fp32: pieces 0..15 = k 0..31 of the step, 16..31 = k 32..63
             const int c = ppos ^ (r & 7);
-            const int kc = min(c * 8, kmax - kt * BK);              // chunks past the padded row end re-read its last chunk (x zero weights)
+            const int kc = AF ? min((p >> 4) * 32 + c * 4, kmax - kt * BK) : min(c * 8, kmax - kt * BK);     // chunks past the row end re-read its last chunk (x zero weights)
             const unsigned off = (unsigned)min(row0 + r, M - 1) * (unsigned)lda + (unsigned)kc;
             __builtin_amdgcn_global_load_lds((gbl_void*)(Ak + off), (lds_void*)(sA + p * 1024), 16, 0, 0);
         }
@@ -169,11 +174,20 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
     f32x4 acc[4][4];
     frag f0a[4], f0b[4], f1a[4], f1b[4];
     auto rd = [&](frag (&af)[4], frag (&bf)[4], int slot, int s) {
-        const unsigned char* sA = smem + slot * Nt2Lds<WN>::SLOT;
-        const unsigned char* sW = sA + Nt2Lds<WN>::A_BYTES;
+        const unsigned char* sA = smem + slot * LD::SLOT;
+        const unsigned char* sW = sA + LD::A_BYTES;
         const int ch = s * 4 + (lane >> 4);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { const int r = wr * 64 + m * 16 + (lane & 15); af[m] = *(const frag*)(sA + r * ROW_BYTES + ((ch ^ (r & 7)) << 4)); }
+        for (int m = 0; m < 4; ++m) {
+            const int r = wr * 64 + m * 16 + (lane & 15);
+            if constexpr (AF) {                                     // image s of the step, chunks 2g and 2g+1 of the row: 8 floats
+                const unsigned char* base = sA + s * (TILE * ROW_BYTES) + r * ROW_BYTES;
+                const int c0 = 2 * (lane >> 4);
+                const f32x4 lo = *(const f32x4*)(base + ((c0 ^ (r & 7)) << 4)), hi = *(const f32x4*)(base + (((c0 + 1) ^ (r & 7)) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af[m][e] = (bf16)lo[e]; af[m][4 + e] = (bf16)hi[e]; }
+            } else af[m] = *(const frag*)(sA + r * ROW_BYTES + ((ch ^ (r & 7)) << 4));
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) { const int r = wc * 64 + n * 16 + (lane & 15); bf[n] = *(const frag*)(sW + r * ROW_BYTES + ((ch ^ (r & 7)) << 4)); }
     };
@@ -261,22 +275,23 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
 
 // Persistent grid: every CU gets its residency's worth of workgroups (2 of 4 waves, or 1 of 8), a multiple of 8 so that a
 // workgroup keeps to one XCD's tile list.
-template <typename Epi, int WN>
+template <typename Epi, int WN, typename AT = bf16>
 static int launch_nt2(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+    typedef Nt2Lds<WN, (int)sizeof(AT)> LD;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt2_kernel<Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, Nt2Lds<WN>::TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt2_kernel<Epi, WN, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LD::TOTAL);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const int gx = (M + TILE - 1) / TILE, gy = (N + 64 * WN - 1) / (64 * WN);
     const int ntiles = ((gx + 7) / 8) * 8 * gy;
     static const int wg_env = getenv("MMVAE_NT2_WGS") ? atoi(getenv("MMVAE_NT2_WGS")) : 0;      // A/B knob: workgroups per CU
-    const int per_cu = wg_env > 0 ? wg_env : (WN == 2 ? 2 : 1);
+    const int per_cu = wg_env > 0 ? wg_env : ((WN == 2 && sizeof(AT) == 2) ? 2 : 1);
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN>), dim3(grid), dim3(128 * WN), Nt2Lds<WN>::TOTAL, st,
-                       (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
+    hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN, AT>), dim3(grid), dim3(128 * WN), LD::TOTAL, st,
+                       (const AT*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
     MM_CHECK_LAUNCH();
     return 0;
 }
