@@ -384,7 +384,47 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
     float n_bad = 0.f;
     if (a.recon_a) s[0] = mse_part<GT, VA>(a, tid0, stride);
     if (a.recon_b) s[1] = bce_part<GT, VD>(a, tid0, stride);
-    if (a.logits) {
+    if (a.logits && a.S <= 32) {
+        // Class term, one row per HALF wave (lane j of the half holds logit j): the row is one coalesced 4 S-byte read, max and
+        // sum are 5-step shuffles, ONE exp per logit serves the loss and the gradient.  (One thread per row -- 24 strided loads
+        // and two exp per logit in a serial loop -- took 25 us of the 35 this kernel needs once the reconstruction terms run
+        // inside the decoder GEMMs.)
+        const int lane_ = threadIdx.x & 63, sub = lane_ & 31, half = lane_ >> 5;
+        const long wave0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2, wstride = (long)gridDim.x * (blockDim.x >> 6) * 2;
+        // CE_U rows per half wave are requested before the first is reduced: the loop is a chain of dependent HBM round trips
+        // otherwise (8 per wave at B = 65 536 and 1024 workgroups: 20 of this kernel's 34 us)
+        constexpr int CE_U = 4;
+        for (long r0 = wave0; r0 < a.B; r0 += wstride * CE_U) {    // wave-uniform trip count
+            float xs[CE_U]; long ys[CE_U];
+#pragma unroll
+            for (int u = 0; u < CE_U; ++u) {
+                const long r = r0 + u * wstride + half;
+                const bool rv = r < a.B;
+                xs[u] = (rv && sub < a.S) ? a.logits[r * a.ld_logits + sub] : -INFINITY;
+                ys[u] = rv ? a.site[r] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < CE_U; ++u) {
+                const long r = r0 + u * wstride + half;
+                const bool rv = r < a.B, ev = rv && sub < a.S;
+                const float x = xs[u];
+                float m = x;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float e = ev ? expf(x - m) : 0.f;
+                float se = e;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+                long y = ys[u];
+                const bool bad = y < 0 || y >= a.S;
+                if (bad) y = 0;
+                const float xy = __shfl(x, (lane_ & 32) + (int)y, 64);
+                const float w = (rv && a.class_weights) ? a.class_weights[y] : 1.f;
+                if (sub == 0 && rv) { s[2] += w * (m + logf(se) - xy); if (bad) n_bad += 1.f; }
+                if (a.g_c && ev) a.g_c[r * a.ld_gc + sub] = a.gamma * w * (e / se - (sub == (int)y ? 1.f : 0.f));
+            }
+        }
+    } else if (a.logits) {
         for (long r = tid0; r < a.B; r += stride) {
             const float* lg = a.logits + r * a.ld_logits;
             long y = a.site[r];

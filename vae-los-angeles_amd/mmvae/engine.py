@@ -398,6 +398,7 @@ class VAEGraph:
         self.overlap_enc = os.environ.get("MMVAE_OVERLAP_ENC", "1") != "0" and self.overlap_dw
         self.overlap_dec = os.environ.get("MMVAE_OVERLAP_DEC", "1") != "0" and self.overlap_dw
         self.overlap_bwd = os.environ.get("MMVAE_OVERLAP_BWD", "1") != "0" and self.overlap_dw
+        self.overlap_noise = os.environ.get("MMVAE_OVERLAP_NOISE", "0") != "0"
         # Training-step fusion (mmvae.graphs): [target or None per decoder].  The next forward then computes those decoders'
         # reconstruction losses inside their last GEMM instead of returning the reconstruction (see DecoderMLP.forward).
         self.fused_recon = None
@@ -444,7 +445,8 @@ class VAEGraph:
         # EncoderB, the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if (self.overlap_enc and xa is not None and xb is not None) else None
-        nside = _side_stream(dev, 1) if (side is not None and self.noise._injected is None) else None
+        # the noise launch alone beside prep_weights' successors: MMVAE_OVERLAP_NOISE=1 (A/B switch)
+        nside = _side_stream(dev, 1) if ((side is not None or self.overlap_noise) and self.noise._injected is None and train) else None
         noise_ev = None
         if nside is not None:
             _fork(main, nside)
@@ -452,7 +454,8 @@ class VAEGraph:
                 masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)
                 for t in masks + [eps]:
                     t.record_stream(main)
-                    t.record_stream(side)
+                    if side is not None:
+                        t.record_stream(side)
                 noise_ev = torch.cuda.Event()
                 noise_ev.record(nside)
         else:
@@ -465,7 +468,7 @@ class VAEGraph:
             with ops.pinned_stream(side if side is not None else main):
                 heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
                                                              st_all[:len(widths_a)] if train else None,
-                                                             masks_ready=(side, noise_ev) if (noise_ev is not None and side is not None) else None)
+                                                             masks_ready=(side if side is not None else main, noise_ev) if noise_ev is not None else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
             heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
