@@ -424,7 +424,7 @@ extern "C" int mmvae_debug_stamps_tn(unsigned long long* out12, int reset) {
 // dW[n][k] += sum_z slab[z][n][k].  Splits are summed in groups of TN_RG (blockIdx.y): ONE group (<= TN_RG splits, the large
 // weight matrices) is a fixed-order sum -> bitwise reproducible gradients; more groups (small matrices split hundreds of
 // ways) add their partial sums with f32 atomics, nsplit / TN_RG ways per address instead of nsplit ways from the GEMM itself.
-constexpr int TN_RG = 32;
+constexpr int TN_RG = 128;     // the wide-tile kernels split the batch 64 and 128 ways: still one fixed-order group
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, int nsplit, long nk, float* __restrict__ dW,
                                                         long ldw, int K) {
     const int z0 = blockIdx.y * TN_RG, z1 = min(nsplit, z0 + TN_RG);
