@@ -50,7 +50,9 @@ def launch_bytes_flops(meta):
     M, N, K = meta["M"], meta["N"], meta["K"]
     if meta["kind"] == "nt":
         byts = M * K * meta["a_bytes"] + (M * K if meta["pro_mask"] else 0) + M * N * meta["c_bytes"]
-        if meta["epi"] != 0:                     # epilogue operand (saved activation / pre-BN output) + mask
+        if meta["epi"] in (3, 4):                # loss epilogue: the fp32 target is read, the bf16 gradient written (c_bytes)
+            byts += M * N * 4
+        elif meta["epi"] != 0:                   # epilogue operand (saved activation / pre-BN output) + mask
             byts += M * N * meta["act_bytes"] + (M * N if meta["epi_mask"] else 0)
         byts += N * K * meta["act_bytes"]
     else:

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r02_prof
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_prof/stats -- python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/r02_prof/bench_under_rocprof.json 2> gpurun_out/r02_prof/bench_under_rocprof.err
-for tag in vae_loss EncoderB.L0.dW DecoderB.L2.dW DecoderB.L2.fwd EncoderB.L0.fwd; do
+for tag in DecoderB.L2.fwd DecoderA.L1.fwd EncoderB.L0.dW EncoderB.L0.fwd DecoderB.L2.dW vae_loss; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r02_pmc_fetch_$tag -- python3 tools/run_dominant.py $tag > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r02_pmc_write_$tag -- python3 tools/run_dominant.py $tag > /dev/null 2>&1
 done

@@ -37,7 +37,17 @@ elif tag == "EncoderB.L0.fwd":         # y[B,512] = b W^T (+ BN statistics)
     pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
     out = torch.empty(M, 512, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, 512, dtype=torch.float64, device=dev)
     run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, 512, 572, out, bias=pl.bias, stats=st)
-elif tag == "DecoderB.L2.fwd":         # recon_b[B,572] = sigmoid(H2 W^T + b), fp32 out
+elif tag in ("DecoderB.L2.fwd", "DecoderA.L1.fwd"):   # the decoders' last layers as the training step runs them: reconstruction loss in the epilogue
+    N, K, bce = (572, 512, True) if tag == "DecoderB.L2.fwd" else (782, 128, False)
+    A = bf(M, K)
+    W = torch.randn(N, K, device=dev) / K ** 0.5; bias = torch.zeros(N, device=dev)
+    pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
+    T = [torch.rand(M, N, device=dev) for _ in range(2)]
+    g = torch.empty(M, ops.ceil_to(N, 8), dtype=torch.bfloat16, device=dev)
+    sums = torch.zeros(5, dtype=torch.float64, device=dev)
+    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, N, K, g, bias=pl.bias, epilogue=ops.EPI_LOSS_BCE_LOGIT if bce else ops.EPI_LOSS_MSE,
+                                h=T[i % 2], loss_sum=sums[1:2] if bce else sums[0:1])
+elif tag == "DecoderB.L2.fwd.store":   # recon_b[B,572] = sigmoid(H2 W^T + b), fp32 out (the public forward)
     A = bf(M, 512)
     W = torch.randn(572, 512, device=dev) / 22; bias = torch.zeros(572, device=dev)
     pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()

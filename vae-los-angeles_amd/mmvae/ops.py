@@ -235,7 +235,7 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
     L.check(L.load().mmvae_gemm_nt(C.byref(g), _stream()), "mmvae_gemm_nt")
     if t0 is not None:
         PROBE.end(tag, t0, dict(kind="nt", M=M, N=N, K=K, a_bytes=a.element_size(),
-                                c_bytes=0 if out is None else out.element_size() + (4 if loss_sum is not None else 0),
+                                c_bytes=0 if out is None else out.element_size(),
                                 pro=prologue is not None, pro_mask=prologue is not None and prologue[2] is not None,
                                 epi=epilogue, epi_mask=bn is not None and bn[4] is not None, act_bytes=2 if prec == PREC_BF16 else 4))
     return out
