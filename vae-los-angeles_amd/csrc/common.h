@@ -73,6 +73,20 @@ template <> struct VLoad<bf16, 2> { static __device__ __forceinline__ void ld(co
 template <> struct VLoad<bf16, 4> { static __device__ __forceinline__ void ld(const bf16* p, float* o) { bf16x4 v = *(const bf16x4*)p; for (int i = 0; i < 4; ++i) o[i] = (float)v[i]; } };
 template <> struct VLoad<bf16, 8> { static __device__ __forceinline__ void ld(const bf16* p, float* o) { bf16x8 v = *(const bf16x8*)p; for (int i = 0; i < 8; ++i) o[i] = (float)v[i]; } };
 
+// One LDS-DMA wave-instruction (64 lanes x 16 bytes -> 1 KB of LDS at `lds_addr`, lane-linear) as inline assembly.  Through
+// __builtin_amdgcn_global_load_lds hipcc's wait-count pass treats later LDS reads as possibly reading the DMA's destination and, in
+// loops that wait with counted s_waitcnt vmcnt(N) of their own, drains every transfer in flight with an s_waitcnt vmcnt(0) right
+// behind the issue or in front of the next one -- a ring deeper than two slots then buys nothing (seen in the ISA of
+// gemm_tn_wide.hip and gemm_nt3.h).  Issued from assembly the transfers are invisible to that pass; the kernel's own counted waits
+// order them (vmcnt counts them in issue order like any other vector-memory operation).  m0 is written: kernels that use this
+// helper must not use the builtin form as well.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(g) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -72,10 +72,10 @@ void gemm_nt3_kernel(const bf16* __restrict__ A, long lda, const bf16* __restric
             const int c = ppos ^ G::g(r);
             const int kc = min(c * 8, kmax - kt * G::BK);          // chunks past the padded row end re-read its last chunk (x zero weights)
             const unsigned offa = (unsigned)min(row0 + r, M - 1) * (unsigned)lda + (unsigned)kc;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Ak + offa), (lds_void*)(sA + p * 1024), 16, 0, 0);
+            lds_dma16(Ak + offa, lds_addr_of(sA + p * 1024));
             const int wrw = (r & ~63) + EC::wrow(r & 63);           // the epilogue's column order inside a wave's 64 columns
             const unsigned offw = (unsigned)min(col0 + wrw, w_rows - 1) * (unsigned)ldw + (unsigned)(c * 8);      // W has ceil128(N) rows
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Wk + offw), (lds_void*)(sW + p * 1024), 16, 0, 0);
+            lds_dma16(Wk + offw, lds_addr_of(sW + p * 1024));
         }
     };
 

@@ -460,7 +460,20 @@ class VAEGraph:
                 noise_ev.record(nside)
         else:
             masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
-        st_all = [t.view(2, -1) for t in zeros_pack(dev, [(2 * w, torch.float64) for w in widths_a + widths_b])] if train else []
+        # ONE memset for everything this step needs zeroed: forward BatchNorm sums, the loss accumulators, and -- when a backward will
+        # follow -- the flat gradient arena with the backward's BatchNorm sums and embedding-table gradient (three fills before)
+        st_all = []
+        if train:
+            specs = [(2 * w, torch.float64) for w in widths_a + widths_b]
+            nst = len(specs)
+            want_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list())
+            if want_bwd:
+                specs += [(5, torch.float64), (5, torch.float32)] + self._grad_specs(xa is not None, xb is not None, site is not None)
+            packed = zeros_pack(dev, specs)
+            st_all = [t.view(2, -1) for t in packed[:nst]]
+            if want_bwd:
+                saved["loss_ws"] = (packed[nst], packed[nst + 1])
+                saved["grad_pack"] = packed[nst + 2:]
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
             if side is not None:
@@ -500,7 +513,7 @@ class VAEGraph:
         fused = None
         want = self.fused_recon
         if want is not None and any(t is not None and self.decoders[i].can_fuse_loss(prec) for i, t in enumerate(want)):
-            sums, out5 = ops.loss_workspace(dev)
+            sums, out5 = saved["loss_ws"] if "loss_ws" in saved else ops.loss_workspace(dev)
             fused = saved["fused_recon"] = {"sums": sums, "out5": out5, "g": {}, "targets": {}}
         for rank_, i in enumerate(order):               # largest decoder on the main stream, the others beside it
             dec = self.decoders[i]
@@ -519,11 +532,21 @@ class VAEGraph:
             _fork(dside, main)
         return outs, mu, logvar, saved
 
-    def alloc_grads(self, device, extra=()):
-        """Flat zeroed gradient arena + views per parameter (+ extra zeroed tensors from the same memset)."""
+    def _grad_specs(self, has_a, has_b, has_site):
+        """zeros_pack specs of what a backward needs zeroed: [flat gradient arena, BatchNorm-backward sums per BN layer, table gradient]."""
+        wa = self.enc_a.widths() if (has_a and self.enc_a is not None) else []
+        wb = self.enc_b.widths() if (has_b and self.enc_b is not None) else []
+        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * self.latent if has_site else 0
+        total = sum(p.numel() for p in self.param_list())
+        return [(total, torch.float32)] + [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)]
+
+    def alloc_grads(self, device, extra=(), packed=None):
+        """Flat zeroed gradient arena + views per parameter (+ extra zeroed tensors from the same memset; `packed`: tensors the
+        forward already zeroed with _grad_specs)."""
         params = self.param_list()
         total = sum(p.numel() for p in params)
-        packed = zeros_pack(device, [(total, torch.float32)] + list(extra))
+        if packed is None:
+            packed = zeros_pack(device, [(total, torch.float32)] + list(extra))
         flat = packed[0]
         views, off = {}, 0
         for p in params:
@@ -545,7 +568,8 @@ class VAEGraph:
         wb = self.enc_b.widths() if "enc_b" in saved else []
         site = saved.get("site")
         n_tab = self.enc_c.embedding.weight.shape[0] * 2 * Ld if site is not None else 0
-        flat, grads, extra = self.alloc_grads(dev, [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)])
+        flat, grads, extra = self.alloc_grads(dev, [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)],
+                                              packed=saved.pop("grad_pack", None))
         st_bwd = [t.view(2, -1) for t in extra[:-1]]
         dzs = []                                       # one dL/dz per decoder; summed in mmvae_fuse_reparam_bwd
         # dW/db GEMMs have no consumer before the optimiser: they run on a second HIP stream beside the dX chain

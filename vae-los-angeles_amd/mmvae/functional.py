@@ -122,7 +122,7 @@ class _LossHandleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, total, stash, *model_outputs):
         ctx.stash = stash
-        return total.clone()
+        return total.view(())            # a view of the kernel's output buffer (not of an input that requires grad): no copy launch
 
     @staticmethod
     @once_differentiable
@@ -243,13 +243,15 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_ga
     if fused is not None:
         sums, out4 = fused["sums"], fused["out5"]         # the decoders' GEMMs have already added their terms
     else:
-        sums, out4 = ops.loss_workspace(dev)              # out4: [total, recon, class, kld, labels out of range]
+        sums = out4 = None                                 # out4: [total, recon, class, kld, labels out of range]
 
     # ---- fused hand-off: all differentiable inputs are outputs of ONE forward of our model --------------------
     tags = [_tag_of(t) for t in (ra, rb, lg, mu, lv) if t is not None and t.requires_grad]
     tag = tags[0][0] if tags and all(t is not None and t[0] is tags[0][0] for t in tags) else None
     if need_grad and tag is not None and not tag["saved"].get("consumed") and "loss_grads" not in tag["saved"]:
         saved = tag["saved"]
+        if sums is None:
+            sums, out4 = saved.pop("loss_ws", None) or ops.loss_workspace(dev)     # zeroed by the forward's one memset
         adt = act_dtype(saved["prec"])
         n_dec = len(saved["dec"])
         g_outs = [None] * n_dec
@@ -289,6 +291,9 @@ def _fused_loss(terms, beta, gamma, class_weights=None, unit_grad=False, beta_ga
         raise RuntimeError("fused reconstruction loss: the loss terms are not all outputs of the one forward that computed it")
 
     # ---- general path --------------------------------------------------------------------------------------------
+    if sums is None:
+        sums, out4 = ops.loss_workspace(dev)
+
     def spec(tensors):
         ga = torch.empty_like(ra_) if (need_grad and ra is not None and ra.requires_grad) else None
         gb = torch.empty_like(rb_) if (need_grad and rb is not None and rb.requires_grad) else None
