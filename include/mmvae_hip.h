@@ -179,8 +179,8 @@ int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd
 int mmvae_embed_table_fwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* b_mu,
                           const float* w_lv, const float* b_lv, float* table, void* stream);
 int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* w_lv,
-                          const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
-                          float* d_b_lv, void* stream);
+                          const float* d_table, int32_t table_copies, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
+                          float* d_b_lv, void* stream);      /* d_table: [table_copies][S][2L] (see mmvae_fuse_bwd_args), summed here */
 
 /* ---------------------------------------------------------------------------------------------
  * Mean-fusion over the modalities present + reparameterisation (vae.py:65-73, 11-15):
@@ -207,7 +207,11 @@ typedef struct {
     const float* eps; const float* logvar;
     float* d_heads; int64_t ld_heads;
     float* d_table; const int64_t* site; int32_t S;  /* may be NULL */
+    int32_t table_copies;   /* d_table is [table_copies][S][2L], zeroed; workgroup w adds into copy w % table_copies (0 = 1).  Every
+                             * workgroup ends with S x 2L atomic adds onto the same addresses: 512 workgroups on ONE copy spent 19 of
+                             * the kernel's 32 us there.  mmvae_embed_table_bwd sums the copies. */
 } mmvae_fuse_bwd_args;
+#define MMVAE_TABLE_COPIES 8
 int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -154,9 +154,16 @@ __global__ __launch_bounds__(256) void embed_table_fwd_kernel(int S, int E, int 
 }
 
 __global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int L, const float* emb, const float* w_mu,
-                                                               const float* w_lv, const float* dT, float* d_emb, float* d_w_mu,
+                                                               const float* w_lv, const float* dTc, int copies, float* d_emb, float* d_w_mu,
                                                                float* d_b_mu, float* d_w_lv, float* d_b_lv) {
     const int L2 = 2 * L;
+    extern __shared__ float dT[];                        // [S][2L]: the copies of the table gradient summed (fixed order)
+    for (int i = threadIdx.x; i < S * L2; i += blockDim.x) {
+        float v = 0.f;
+        for (int c = 0; c < copies; ++c) v += dTc[(long)c * S * L2 + i];
+        dT[i] = v;
+    }
+    __syncthreads();
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     // the three products are independent: one index space [dEmb | dWcat | db], so their (latency-bound) dot products of
     // 20-24 terms run side by side instead of one phase after the other
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
     const int L2 = 2 * a.L;
     if (use_lds) { for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) sT[i] = 0.f; __syncthreads(); }
     const int b0 = blockIdx.x * rows_per_block, b1 = min(a.B, b0 + rows_per_block);
+    float* dtab = a.d_table ? a.d_table + (long)(blockIdx.x % (a.table_copies > 0 ? a.table_copies : 1)) * a.S * L2 : nullptr;
     const float inv_n = 1.f / (float)a.n_mod;
     // U elements per thread are loaded before any is processed (stores may alias loads for the compiler): with one element
     // per iteration a thread had ~7 dependent-latency loads in flight at a time and the launch was latency-bound (43 us for 40 MB)
@@ -250,13 +258,13 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
             if (a.d_table && sidx[u] >= 0) {
                 const long sx = sidx[u];
                 if (use_lds) { atomicAdd(&sT[sx * L2 + l], dmu); atomicAdd(&sT[sx * L2 + a.L + l], dlv); }
-                else { unsafeAtomicAdd(&a.d_table[sx * L2 + l], dmu); unsafeAtomicAdd(&a.d_table[sx * L2 + a.L + l], dlv); }
+                else { unsafeAtomicAdd(&dtab[sx * L2 + l], dmu); unsafeAtomicAdd(&dtab[sx * L2 + a.L + l], dlv); }
             }
         }
     }
     if (use_lds && a.d_table) {
         __syncthreads();
-        for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) if (sT[i] != 0.f) unsafeAtomicAdd(&a.d_table[i], sT[i]);
+        for (int i = threadIdx.x; i < a.S * L2; i += blockDim.x) if (sT[i] != 0.f) unsafeAtomicAdd(&dtab[i], sT[i]);
     }
 }
 
@@ -628,7 +636,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 14; }
+extern "C" int mmvae_abi_version(void) { return 15; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -691,11 +699,14 @@ extern "C" int mmvae_embed_table_fwd(int32_t S, int32_t E, int32_t L, const floa
 }
 
 extern "C" int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const float* emb, const float* w_mu, const float* w_lv,
-                                     const float* d_table, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
+                                     const float* d_table, int32_t table_copies, float* d_emb, float* d_w_mu, float* d_b_mu, float* d_w_lv,
                                      float* d_b_lv, void* stream) {
     if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !w_lv || !d_table || !d_emb || !d_w_mu || !d_b_mu || !d_w_lv || !d_b_lv) return MMVAE_ERR_ARG;
+    if (table_copies < 1) table_copies = 1;
+    const size_t lds = (size_t)S * 2 * L * sizeof(float);
+    if (lds > 48 * 1024) return MMVAE_ERR_ARG;
     const int work = S * E + 2 * L * E + 2 * L;          // one output element per thread
-    hipLaunchKernelGGL(embed_table_bwd_kernel, dim3((work + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
+    hipLaunchKernelGGL(embed_table_bwd_kernel, dim3((work + 255) / 256), dim3(256), lds, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, table_copies, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
     MM_CHECK_LAUNCH();
     return 0;
 }

@@ -9,11 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 PRO_NONE, PRO_BN_RELU_DROP, PRO_BN_BWD_APPLY = 0, 1, 2
+TABLE_COPIES = 8          # MMVAE_TABLE_COPIES
 EPI_STORE, EPI_RELU_MASK, EPI_BN_BWD, EPI_LOSS_MSE, EPI_LOSS_BCE_LOGIT = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TILE = 128
@@ -84,7 +85,7 @@ class FuseBwdArgs(C.Structure):
                 ("g_mu", vp), ("g_lv", vp), ("dz", vp), ("dz2", vp), ("dz3", vp), ("lddz", i64),
                 ("eps", vp), ("logvar", vp),
                 ("d_heads", vp), ("ld_heads", i64),
-                ("d_table", vp), ("site", vp), ("S", i32)]
+                ("d_table", vp), ("site", vp), ("S", i32), ("table_copies", i32)]
 
 
 class LossArgs(C.Structure):
@@ -121,7 +122,7 @@ _SIGNATURES = {
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],
     "mmvae_bn_bwd_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp],
     "mmvae_embed_table_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
-    "mmvae_embed_table_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mmvae_embed_table_bwd": [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
     "mmvae_fuse_reparam_fwd": [C.POINTER(FuseFwdArgs), vp],
     "mmvae_fuse_reparam_bwd": [C.POINTER(FuseBwdArgs), vp],
     "mmvae_vae_loss": [C.POINTER(LossArgs), vp],

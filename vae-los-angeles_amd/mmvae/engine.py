@@ -536,7 +536,7 @@ class VAEGraph:
         """zeros_pack specs of what a backward needs zeroed: [flat gradient arena, BatchNorm-backward sums per BN layer, table gradient]."""
         wa = self.enc_a.widths() if (has_a and self.enc_a is not None) else []
         wb = self.enc_b.widths() if (has_b and self.enc_b is not None) else []
-        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * self.latent if has_site else 0
+        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * self.latent * L_.TABLE_COPIES if has_site else 0
         total = sum(p.numel() for p in self.param_list())
         return [(total, torch.float32)] + [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)]
 
@@ -567,7 +567,7 @@ class VAEGraph:
         wa = self.enc_a.widths() if "enc_a" in saved else []
         wb = self.enc_b.widths() if "enc_b" in saved else []
         site = saved.get("site")
-        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * Ld if site is not None else 0
+        n_tab = self.enc_c.embedding.weight.shape[0] * 2 * Ld * L_.TABLE_COPIES if site is not None else 0
         flat, grads, extra = self.alloc_grads(dev, [(2 * w, torch.float64) for w in wa + wb] + [(max(n_tab, 1), torch.float32)],
                                               packed=saved.pop("grad_pack", None))
         st_bwd = [t.view(2, -1) for t in extra[:-1]]
@@ -628,7 +628,7 @@ class VAEGraph:
             self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
         n_mod = saved["n_mod"]
         d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
-        d_table = extra[-1][:n_tab].view(-1, 2 * Ld) if site is not None else None
+        d_table = extra[-1][:n_tab].view(L_.TABLE_COPIES, -1, 2 * Ld) if site is not None else None
         ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, saved["eps"], saved["logvar"], d_heads, d_table, site)
         if "enc_a" in saved:
             self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)], train=saved["train"])

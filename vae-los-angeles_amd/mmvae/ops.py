@@ -349,9 +349,11 @@ def embed_table_fwd(emb, w_mu, b_mu, w_lv, b_lv, table):
 
 
 def embed_table_bwd(emb, w_mu, w_lv, d_table, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv):
+    """d_table: [S][2L] or [copies][S][2L] (the copies mmvae_fuse_reparam_bwd scattered into; summed here)."""
     S, E = emb.shape
+    copies = d_table.shape[0] if d_table.dim() == 3 else 1
     L.check(L.load().mmvae_embed_table_bwd(S, E, w_mu.shape[0], emb.data_ptr(), w_mu.data_ptr(), w_lv.data_ptr(),
-                                           d_table.data_ptr(), d_emb.data_ptr(), d_w_mu.data_ptr(), d_b_mu.data_ptr(),
+                                           d_table.data_ptr(), copies, d_emb.data_ptr(), d_w_mu.data_ptr(), d_b_mu.data_ptr(),
                                            d_w_lv.data_ptr(), d_b_lv.data_ptr(), _stream()), "mmvae_embed_table_bwd")
 
 
@@ -366,10 +368,12 @@ def fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z):
 
 
 def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_table, site):
-    """dzs: 1..3 fp32 (B, Ld) tensors with one leading dimension (dL/dz of each decoder); they are summed."""
+    """dzs: 1..3 fp32 (B, Ld) tensors with one leading dimension (dL/dz of each decoder); they are summed.
+    d_table: zeroed [S][2L] or [copies][S][2L] (workgroups spread their scatter-adds over the copies)."""
     dzs = list(dzs) + [None] * (3 - len(dzs))
+    copies = d_table.shape[0] if (d_table is not None and d_table.dim() == 3) else 1
     a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dzs[0].data_ptr(), _p(dzs[1]), _p(dzs[2]), _ld(dzs[0]), eps.data_ptr(), logvar.data_ptr(),
-                      d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[0] if d_table is not None else 0)
+                      d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[-2] if d_table is not None else 0, copies)
     n_dz = sum(1 for d in dzs if d is not None)
     with probe_span("fuse_reparam_bwd", B * Ld * 4 * (n_dz + (g_mu is not None) + (g_lv is not None) + 2 + 2)):
         L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
