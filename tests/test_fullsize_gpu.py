@@ -121,3 +121,38 @@ def test_bench_configuration_first_step_vs_cpu_reference():
     np.testing.assert_allclose(got[3], want[3], rtol=2e-2)                       # KL: a small difference of O(1) terms, noise-sensitive
     exp = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_expect.json")))
     np.testing.assert_allclose(got[0], exp["first_step_total"], rtol=exp["rtol_first"])
+
+
+def test_fused_training_step_at_batch_65536_equals_the_public_call_sequence(case):
+    """What bench.py times is the captured step with the reconstruction losses inside the decoders' last GEMMs
+    (engine.VAEGraph.fused_recon); the oracle comparisons above drive the public model() + vae_loss() sequence.  At B = 65 536, same
+    parameters and injected noise: loss terms equal to 1e-7 (summation order), every parameter gradient equal to the order of its
+    atomic accumulations -- so the oracle parity above carries over to the timed path."""
+    from mmvae import functional as F_
+    model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), case["P"], case["Bf"]).to(DEV).set_precision("bf16").train()
+    a, b, site = t(case["a"]), t(case["b"]), t(case["site"])
+
+    def step(fuse):
+        engine.GLOBAL_NOISE.inject(masks_list(case["masks"]), torch.from_numpy(case["eps"]))
+        g = model._graph()
+        g.fused_recon = [a, b, None] if fuse else None
+        try:
+            ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+        finally:
+            g.fused_recon = None
+            engine.GLOBAL_NOISE.clear()
+        for m in model.modules():                                    # the second forward must see the same running statistics
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        total, out5 = F_.fused_loss({"a": (ra, a), "b": (rb, b), "c": (rc, site), "kl": (mu, lv)}, 1e-3, 1.0)
+        for p in model.parameters():
+            p.grad = None
+        total.backward()
+        return np.array(F_.read_losses(out5)), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    l0, g0 = step(False)
+    l1, g1 = step(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    worst = max(float((g0[k] - g1[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-30) for k in g0 if float(g0[k].abs().max()) > 1e-6 * max(float(v.abs().max()) for v in g0.values()))
+    report(f"B=65536 bf16: fused step (loss in the decoder GEMMs) vs public call sequence: loss rel {np.abs(l1 / l0 - 1).max():.1e}, gradients max rel {worst:.1e}")
+    assert worst <= 1e-3
