@@ -65,6 +65,9 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
 /* ---------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( prologue(A)[M,K] x W[N,K]^T )          (gemm_nt.hip)
  *   W        prepared operand [ceil128(N)][ceil64(K)] in compute type, ldw % 64 == 0
+ *   h, masks are [M][ld] matrices: a kernel may READ a whole row of ld elements from a row's first element (tiles are loaded in
+ *            full 128-byte lines).  For a column slice of a wider buffer that reaches past the slice's row end -- harmless inside the
+ *            buffer, so the buffer's tail must extend 512 bytes beyond its last row (mmvae.engine pads the merged decoder stem)
  *   prologue MMVAE_PRO_BN_RELU_DROP: A is the previous layer's PRE-BatchNorm output (activation
  *            type); the kernel applies relu(A*pro_scale[k]+pro_shift[k]) * keep/(1-p) on the fly
  *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask], bytes 0 or 1 (mmvae_noise), or NULL.

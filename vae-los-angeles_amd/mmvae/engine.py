@@ -135,6 +135,7 @@ _ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.uint8: 1, torch.int64: 8}
 
 
 _SIDE_STREAMS = {}
+_MERGE_DECODER_STEM = os.environ.get("MMVAE_NO_DECODER_STEM") is None          # A/B switch
 
 
 def _side_stream(device, which=0):
@@ -326,15 +327,21 @@ class DecoderMLP:
         (bf16 A operand) and more than one K step."""
         return prec == ops.PREC_BF16 and len(self.pl) >= 2 and self.pl[-1].K > 64
 
-    def forward(self, prec, z, fused_loss=None):
+    def forward(self, prec, z, fused_loss=None, first=None):
         """fused_loss = (target fp32 [B][N], one-element float64 accumulator): the last layer does not store its output; its GEMM
         epilogue adds the reconstruction loss (sum-MSE, or sum-BCE behind the final Sigmoid: losses.py:31,34) to the accumulator and
-        writes the bf16 gradient w.r.t. the pre-activation output.  Returns (gradient, acts) then instead of (output, acts)."""
+        writes the bf16 gradient w.r.t. the pre-activation output.  Returns (gradient, acts) then instead of (output, acts).
+        first: output of layer 0 computed elsewhere (VAEGraph's merged first layers of all decoders), a [B][N0] column slice."""
         B, dev = z.shape[0], z.device
         adt = act_dtype(prec)
         acts = [z]
         h = z
+        if first is not None:
+            acts.append(first)
+            h = first
         for j, pl in enumerate(self.pl):
+            if j == 0 and first is not None:
+                continue
             last = j == len(self.pl) - 1
             if last and fused_loss is not None:
                 target, acc = fused_loss
@@ -353,10 +360,12 @@ class DecoderMLP:
             h = out
         return h, acts
 
-    def backward(self, prec, acts, out, g_out, g_is_logit_grad, dz, accumulate_dz, grads, tn=ops.gemm_tn):
+    def backward(self, prec, acts, out, g_out, g_is_logit_grad, dz, accumulate_dz, grads, tn=ops.gemm_tn, d0_out=None):
         """g_out: gradient w.r.t. the decoder output ([B][>=N], fp32 or activation type).  For a
-        sigmoid decoder it is w.r.t. the pre-sigmoid logits iff g_is_logit_grad."""
-        B, dev = dz.shape[0], dz.device
+        sigmoid decoder it is w.r.t. the pre-sigmoid logits iff g_is_logit_grad.
+        d0_out: where the gradient w.r.t. layer 0's output goes (a column slice of the buffer VAEGraph multiplies with the merged
+        first-layer weights of all decoders); layer 0's own dX GEMM is then skipped and dz is not touched."""
+        B, dev = g_out.shape[0], g_out.device
         adt = act_dtype(prec)
         d = g_out
         if self.final_sigmoid and not g_is_logit_grad:
@@ -367,10 +376,10 @@ class DecoderMLP:
             pl, lin = self.pl[j], self.linears[j]
             tn(prec, d, acts[j], grads[lin.weight], grads[lin.bias], pl.N, pl.K, tag=f"{self.name}.L{j}.dW")
             if j > 0:
-                d_prev = torch.empty(B, ceil_to(pl.K, 8), dtype=adt, device=dev)
+                d_prev = d0_out if (j == 1 and d0_out is not None) else torch.empty(B, ceil_to(pl.K, 8), dtype=adt, device=dev)
                 ops.gemm_nt(prec, d, pl.wt, pl.K, pl.N, d_prev, epilogue=EPI_RELU_MASK, h=acts[j], tag=f"{self.name}.L{j}.dX")
                 d = d_prev
-            else:
+            elif d0_out is None:
                 ops.gemm_nt(prec, d, pl.wt, pl.K, pl.N, dz, accumulate=accumulate_dz, tag=f"{self.name}.L{j}.dX")
 
 
@@ -389,6 +398,7 @@ class VAEGraph:
         self.latent = (enc_a or enc_b or enc_c).latent
         self._prep = None
         self._prep_key = None
+        self.dec_stem = None
         self.noise = GLOBAL_NOISE
         self.grad_sync = None          # mmvae.parallel.GradAllReduce (early/final hooks) under data parallelism
         # Independent chains on side HIP streams (EncoderA beside EncoderB, the small decoders beside DecoderB, the dW GEMMs beside
@@ -415,6 +425,15 @@ class VAEGraph:
             pls = []
             for b in self.blocks:
                 pls += b.prepare(prec, device)
+            # The first layers of all decoders read the same z (K = latent: one K step): ONE GEMM with their weights concatenated
+            # along N instead of one latency-bound launch per decoder, and ONE dX GEMM (K = sum of their widths) for dL/dz in
+            # backward.  Each decoder continues from / writes into its column slice (widths must keep the slices 16-byte aligned).
+            self.dec_stem = None
+            decs = self.decoders
+            if (_MERGE_DECODER_STEM and len(decs) >= 2 and all(isinstance(d, DecoderMLP) and len(d.linears) >= 2 for d in decs)
+                    and all(d.linears[0].in_features == decs[0].linears[0].in_features and d.linears[0].out_features % 8 == 0 for d in decs)):
+                self.dec_stem = ops.PreparedLinear([d.linears[0].weight for d in decs], [d.linears[0].bias for d in decs], prec, device)
+                pls.append(self.dec_stem)
             self._prep = ops.WeightPrep(pls, device)
             self._prep_key = key
         self._prep.run()
@@ -510,6 +529,18 @@ class VAEGraph:
         dside = _side_stream(dev) if (self.overlap_dec and len(order) > 1) else None
         if dside is not None:
             _fork(main, dside)
+        stem = self.dec_stem
+        firsts = [None] * len(self.decoders)
+        if stem is not None:
+            # Tail padding: a consumer's epilogue loads the saved activation of a whole 128- / 256-column tile in full-line layout when
+            # the tile fits the LEADING DIMENSION -- for the last column slice that runs past the row end, i.e. for the last row past
+            # the buffer (a fault when the allocation ends on a page boundary, as 65 536 x 448 bf16 does).  What is read there is never used.
+            H0 = torch.empty(B * stem.N + 1024, dtype=act_dtype(prec), device=dev)[:B * stem.N].view(B, stem.N)
+            ops.gemm_nt(prec, z, stem.w, stem.N, stem.K, H0, bias=stem.bias, act=ACT_RELU, tag="Decoders.L0.fwd")
+            off = 0
+            for i, d in enumerate(self.decoders):
+                firsts[i] = H0[:, off:off + d.linears[0].out_features]
+                off += d.linears[0].out_features
         fused = None
         want = self.fused_recon
         if want is not None and any(t is not None and self.decoders[i].can_fuse_loss(prec) for i, t in enumerate(want)):
@@ -521,11 +552,11 @@ class VAEGraph:
             with ops.pinned_stream(dside if (dside is not None and rank_ > 0) else main):
                 if tgt is not None:
                     k = 1 if dec.final_sigmoid else 0                     # sums[0] = MSE, sums[1] = BCE (mmvae_vae_loss)
-                    g, acts = dec.forward(prec, z, fused_loss=(tgt, fused["sums"][k:k + 1]))
+                    g, acts = dec.forward(prec, z, fused_loss=(tgt, fused["sums"][k:k + 1]), first=firsts[i])
                     fused["g"][i], fused["targets"][i] = g, tgt
                     o = torch.empty(1, dtype=torch.float32, device=dev).expand(B, dec.out_dim)     # placeholder: no storage behind it
                 else:
-                    o, acts = dec.forward(prec, z)
+                    o, acts = dec.forward(prec, z, first=firsts[i])
             outs[i] = o
             saved["dec"][i] = (acts, o.detach())
         if dside is not None:
@@ -608,14 +639,25 @@ class VAEGraph:
                 keep.extend(kw.get("p_prologue") or ())
                 with ops.pinned_stream(side):
                     ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
-        first = True
+        stem = self.dec_stem if all(g is not None for g in g_outs) else None      # every decoder must fill its slice
+        D0, off = None, 0
+        if stem is not None:
+            D0 = torch.empty(B, stem.N, dtype=act_dtype(prec), device=dev)
         for dec, (acts, out), g, is_logit in zip(self.decoders, saved["dec"], g_outs, g_logit_flags):
             if g is None:
+                continue
+            if stem is not None:
+                n0 = dec.linears[0].out_features
+                dec.backward(prec, acts, out, g, is_logit, None, False, grads, tn, d0_out=D0[:, off:off + n0])
+                off += n0
                 continue
             dz = torch.empty(B, Ld, dtype=torch.float32, device=dev)
             dec.backward(prec, acts, out, g, is_logit, dz, False, grads, tn)
             dzs.append(dz)
-            first = False
+        if stem is not None:
+            dz = torch.empty(B, Ld, dtype=torch.float32, device=dev)
+            ops.gemm_nt(prec, D0, stem.wt, stem.K, stem.N, dz, tag="Decoders.L0.dX")
+            dzs.append(dz)
         if not dzs:
             dzs.append(torch.zeros(B, Ld, dtype=torch.float32, device=dev))
         flush_tiny("tiny_dW.decoders")
