@@ -660,7 +660,8 @@ class VAEGraph:
             dzs.append(dz)
         if not dzs:
             dzs.append(torch.zeros(B, Ld, dtype=torch.float32, device=dev))
-        flush_tiny("tiny_dW.decoders")
+        if self.grad_sync is not None:                    # data parallel: the decoder gradients must be final for the early all-reduce bucket;
+            flush_tiny("tiny_dW.decoders")                # otherwise they wait for the encoder heads and share ONE grouped launch + reduce
         if self.grad_sync is not None:
             if side is not None:                          # the decoder dW launches live on the side stream
                 ev = torch.cuda.Event()
