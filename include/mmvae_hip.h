@@ -43,7 +43,7 @@ int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes bindi
  * 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32 at the scaled omics widths) is processed in row blocks of
  * at most half that threshold (2 GiB) inside the entry point; key 3 lowers it so that tests reach that path at moderate sizes;
  * key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off; key 5 = LDS-DMA form of the NT kernel for fp32 A
- * operands (gemm_nt2.h) on/off (default off: measured equal). */
+ * operands (gemm_nt2.h) on/off (default off: measured equal); key 6 = row-coalesced LDS form of the BatchNorm-backward dX epilogue on/off. */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------

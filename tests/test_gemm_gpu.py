@@ -397,3 +397,43 @@ def test_nt_fp32_operand_by_lds_dma_is_bit_identical():
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-9 * float(res[0][1].abs().max())
     ref = _round(A, PREC_BF16).double().cpu() @ _round(W, PREC_BF16).double().cpu().t() + pl.bias.double().cpu()
     assert float((res[1][0].double().cpu() - ref).abs().max()) <= _tol(K, float(ref.abs().max()), out_bf16=True)
+
+
+@pytest.mark.parametrize("M,N,K,with_mask", [(1000, 512, 256, True), (777, 208, 128, True), (4096, 256, 192, False)])
+def test_bn_bwd_epilogue_row_coalesced_form(M, N, K, with_mask):
+    """BatchNorm+ReLU+Dropout backward epilogue of the dX GEMM (phase 2: store d, sums of d and d*xhat) in the row-coalesced LDS
+    form of the second-generation kernel (mmvae_set_tuning key 6) against the accumulator-layout form and against float64:
+    same d bits (same arithmetic on the same accumulators), statistics equal to summation order."""
+    from mmvae import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    pl = _prep(W.to(DEV), torch.zeros(N, device=DEV), PREC_BF16)
+    Np = ops.ceil_to(N, 8)
+    Y = torch.zeros(M, Np, dtype=torch.bfloat16); Y[:, :N] = torch.randn(M, N, generator=g).bfloat16(); Y = Y.to(DEV)
+    mask = (torch.rand(M, ops.ceil_to(N, 16), generator=g) > 0.1).to(torch.uint8).to(DEV) if with_mask else None
+    f = lambda: (torch.rand(N, generator=g) + 0.5).to(DEV)
+    sc, sh, mu, rs = f(), f() - 1.0, f() - 1.0, f()
+    res = []
+    try:
+        for on in (0, 1):
+            lib.mmvae_set_tuning(6, on)
+            d = torch.full((M, Np), 5.0, dtype=torch.bfloat16, device=DEV)
+            st = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+            ops.gemm_nt(PREC_BF16, A, pl.wt if False else pl.w, N, K, d, epilogue=ops.EPI_BN_BWD, h=Y, bn=(sc, sh, mu, rs, mask, 1.0 / 0.9), bn_phase=2, stats=st)
+            res.append((d, st))
+    finally:
+        lib.mmvae_set_tuning(6, 1)
+    assert torch.equal(res[0][0][:, :N].view(torch.int16), res[1][0][:, :N].view(torch.int16))
+    assert float(res[1][0][:, N:].float().abs().max() if Np > N else 0.0) == 0.0                    # pad columns zeroed
+    scale = res[0][1].abs().max(dim=1, keepdim=True).values
+    assert float(((res[0][1] - res[1][1]).abs() / scale).max()) <= 1e-5
+    acc = A.double().cpu() @ _round(W, PREC_BF16).double().t()
+    y = Y[:, :N].double().cpu()
+    keep = (mask[:, :N].double().cpu() / 0.9) if with_mask else 1.0
+    dref = torch.where(y * sc.double().cpu() + sh.double().cpu() > 0, acc * keep, torch.zeros_like(acc))
+    xh = (y - mu.double().cpu()) * rs.double().cpu()
+    assert float((res[1][0][:, :N].double().cpu() - dref).abs().max()) <= _tol(K, float(dref.abs().max()), out_bf16=True)
+    ref_st = torch.stack([dref.sum(0), (dref * xh).sum(0)])
+    assert float((res[1][1].cpu() - ref_st).abs().max()) <= 3e-5 * np.sqrt(M) * float(ref_st.abs().max()) + 1e-3

@@ -310,6 +310,7 @@ template <> struct IsPlainF32x4<SrcPlain<bf16, float, 4>> { static constexpr boo
 // measured equal to the register staging on EncoderB.L0.fwd (96 vs 97-101 us, tools/bench_ntf32.py; the layer is bound by the 64 KB
 // of A + W a CU ingests per K step either way): off by default, kept as the A/B arm (mmvae_set_tuning key 5, MMVAE_NT2_F32=1)
 static int g_nt2_f32 = getenv("MMVAE_NT2_F32") ? 1 : 0;
+static int g_bnbwd_stream = getenv("MMVAE_NO_BNBWD_STREAM") ? 0 : 1;          // mmvae_set_tuning key 6
 template <typename T> struct IsPlainBf16 { static constexpr bool value = false; };
 template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool value = true; };
 
@@ -383,6 +384,15 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
             if (a->ldh % 8 || ((uintptr_t)a->h & 15)) return MMVAE_ERR_ARG;
             if (a->bn_phase && (a->ldc % 8 || ((uintptr_t)a->c & 15))) return MMVAE_ERR_ARG;
             if (a->epi_mask && (a->N % 16 || a->ld_epi_mask % 16 || ((uintptr_t)a->epi_mask & 15))) return MMVAE_ERR_ARG;
+        }
+        if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
+            // phase 2 (store d + statistics) on plain bf16 operands with at least two K steps: row-coalesced LDS epilogue (gemm_nt2.h)
+            if (g_bnbwd_stream && g_nt2_on && a->bn_phase == 2 && a->K > 64 && a->ldh % 4 == 0 && a->ldc % 4 == 0 &&
+                (!a->epi_mask || (a->ld_epi_mask % 4 == 0 && ((uintptr_t)a->epi_mask & 3) == 0)) && ((uintptr_t)a->h & 7) == 0 && ((uintptr_t)a->c & 7) == 0) {
+                EpiBnBwdStream e{(bf16*)a->c, a->ldc, (const bf16*)a->h, a->ldh, a->epi_mask, a->ld_epi_mask,
+                                 a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd, a->epi_inv_keep, a->stat1, a->stat2};
+                return launch_nt2<EpiBnBwdStream, 2>(src.p, src.lda, a->w, a->ldw, a->M, a->N, a->K, e, st);
+            }
         }
         EpiBnBwd<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, a->epi_mask, a->ld_epi_mask,
                            a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd, a->epi_inv_keep, a->bn_coef, a->bn_phase,
@@ -458,6 +468,7 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     }
     if (key == 4) { mm::tn_wide_enable(value); return 0; }
     if (key == 5) { mm::g_nt2_f32 = value; return 0; }
+    if (key == 6) { mm::g_bnbwd_stream = value; return 0; }
     return MMVAE_ERR_ARG;
 }
 

@@ -111,6 +111,78 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
     }
 }
 
+// BatchNorm-backward dX epilogue in the same row-coalesced form (EpiBnBwdStream): thread (row r0 + 8 i, 4 columns) loads 8 bytes of
+// the saved pre-BN output y and 4 mask bytes per pass, computes d = acc * keep * (y*scale + shift > 0) and xhat, keeps its four
+// columns' partial sums of d and d*xhat in registers over its 16 rows (no butterfly), stores bf16 d; the 8 row groups are added
+// through LDS and each column's two sums go out as f64 atomics.  The accumulator-layout form (gemm_nt_epi.h) ran EncoderB.L0.dX at
+// 2.2 TB/s on its 200 MB.
+template <typename Epi, int WN>
+__device__ __forceinline__ void nt2_bnbwd_epilogue(unsigned char* smem, const float* ecol, float* red, f32x4 (&acc)[4][4], const Epi& epi,
+                                                   int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
+{
+    static_assert(WN == 2, "128 x 128 tiles: the fp32 tile is exactly the 64 KB ring");
+    constexpr int BN = 128;
+    const int li = lane & 15, lg = lane >> 4;
+    const int c = tid & 31, r0 = tid >> 5;
+    const int colg = col0 + 4 * c;
+    const bf16* __restrict__ Y = epi.Y;
+    const uint8_t* __restrict__ K_ = epi.mask;
+    bf16* __restrict__ C = epi.C;
+    const bool has_mask = K_ != nullptr;
+    const int cy = min(colg, (int)epi.ldy - 4);                      // y rows are padded to 8 columns: a 4-column load inside ldy is in bounds
+    bf16x4 yv[16]; uint32_t mv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long grow = min(row0 + r0 + 8 * i, M - 1);
+        yv[i] = *(const bf16x4*)(Y + grow * epi.ldy + cy);
+        mv[i] = has_mask ? *(const uint32_t*)(K_ + grow * epi.ldm + min(colg, (int)epi.ldm - 4)) : 0x01010101u;
+    }
+    __syncthreads();                                               // every wave has finished reading the ring
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wr * 64 + m * 16 + li, ch = 16 * wc + 4 * n + lg;
+            *(f32x4*)(smem + row * 512 + ((ch ^ (row & 7)) << 4)) = acc[m][n];
+        }
+    __syncthreads();
+    const int ccols = (int)min((long)((N + 7) & ~7), epi.ldc);
+    const unsigned char* src = smem + r0 * 512 + ((c ^ (r0 & 7)) << 4);
+    float sc[4], sh[4], mu[4], rs[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = ecol[4 * c + e]; sh[e] = ecol[BN + 4 * c + e]; mu[e] = ecol[2 * BN + 4 * c + e]; rs[e] = ecol[3 * BN + 4 * c + e]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int grow = row0 + r0 + 8 * i;
+        const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = grow < M && colg + e < N;
+            const float y = (float)yv[i][e];
+            const float keep = ((mv[i] >> (8 * e)) & 0xffu) ? epi.inv_keep : 0.f;
+            const float d = (ok && y * sc[e] + sh[e] > 0.f) ? z[e] * (has_mask ? keep : 1.f) : 0.f;
+            const float xh = (y - mu[e]) * rs[e];
+            s1[e] += d; s2[e] += d * xh;
+            o[e] = (bf16)d;
+        }
+        if (grow < M && colg < ccols) *(bf16x4*)(C + (long)grow * epi.ldc + colg) = o;
+    }
+    __syncthreads();                                               // everybody is done with the LDS tile: reuse it for the column sums
+    float* part = (float*)smem;                                    // [8 row groups][2][128 columns]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { part[(r0 * 2 + 0) * BN + 4 * c + e] = s1[e]; part[(r0 * 2 + 1) * BN + 4 * c + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 2 * BN) {
+        const int which = tid >> 7, col = tid & (BN - 1);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += part[(g * 2 + which) * BN + col];
+        if (col0 + col < N) unsafeAtomicAdd((which ? epi.stat2 : epi.stat1) + col0 + col, (double)v);
+    }
+    __syncthreads();                                               // the ring may be refilled
+}
+
 template <typename Epi, int WN, typename AT = bf16>
 __global__ __launch_bounds__(128 * WN, 2)
 void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
@@ -249,7 +321,8 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // epilogue operands (saved activation, keep mask): fetched here, not a K step early as the first generation does -- 48
         // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
         if constexpr (Epi::LDS_STREAM) {
-            nt2_loss_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+            if constexpr (Epi::MODE == 2) nt2_bnbwd_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+            else nt2_loss_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
             if (Tn >= 0) issue(Tn, 0, g & 1);                       // the ring is free again (the epilogue ends in a barrier)
         } else {
             nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);

@@ -144,6 +144,26 @@ struct EpiLoss {
     }
 };
 
+// BatchNorm+ReLU+Dropout backward around a dX contraction (EpiBnBwd phase 2: store d, accumulate sum d and sum d*xhat) in the
+// row-coalesced LDS form of the second-generation kernel (gemm_nt2.h, nt2_bnbwd_epilogue): bf16 y / d, uint8 keep mask.
+struct EpiBnBwdStream {
+    static constexpr bool STATS = true;
+    static constexpr bool LDS_STREAM = true;
+    static constexpr int NEED = 0;
+    static constexpr int MODE = 2;                    // 0 / 1: the loss epilogues
+    typedef float out_t; typedef float h_t;           // 4-byte accumulator layout (see EpiLoss)
+    bf16* C; long ldc; const bf16* Y; long ldy; const uint8_t* mask; long ldm;
+    const float* scale; const float* shift; const float* mean; const float* rstd; float inv_keep;
+    double* stat1; double* stat2;
+    struct Col { float b; };
+    static constexpr int NCOL = 4;                    // scale, shift, mean, rstd of the tile's columns
+    bool accumulate_requested() const { return false; }
+    __device__ __forceinline__ void fill(float* e, int BN, int cl, int c, int N) const {
+        const bool ok = c < N;
+        e[cl] = ok ? scale[c] : 0.f; e[BN + cl] = ok ? shift[c] : 0.f; e[2 * BN + cl] = ok ? mean[c] : 0.f; e[3 * BN + cl] = ok ? rstd[c] : 0.f;
+    }
+};
+
 // Column order of a wave's 64 output columns inside its 4 MFMA n-tiles.
 template <bool PAIR> struct EpiCols {
     static constexpr int G = PAIR ? 8 : 4;            // consecutive columns a lane owns per group
