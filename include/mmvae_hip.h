@@ -210,6 +210,9 @@ typedef struct {
     const float* eps; const float* logvar;
     float* d_heads; int64_t ld_heads;
     float* d_table; const int64_t* site; int32_t S;  /* may be NULL */
+    void* d_heads_lp; int64_t ld_heads_lp;   /* optional bf16 copy of d_heads ([B][>= 2L], pad columns zeroed): the A operand of the heads' dX
+                                              * GEMMs in bf16 mode (they round d_heads to bf16 on load anyway), which lets them run the
+                                              * LDS-DMA kernel with the row-coalesced BatchNorm-backward epilogue */
     int32_t table_copies;   /* d_table is [table_copies][S][2L], zeroed; workgroup w adds into copy w % table_copies (0 = 1).  Every
                              * workgroup ends with S x 2L atomic adds onto the same addresses: 512 workgroups on ONE copy spent 19 of
                              * the kernel's 32 us there.  mmvae_embed_table_bwd sums the copies. */

@@ -270,6 +270,11 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(mmvae_fuse_bwd_args a, in
             if (a.n_mod > 1) { dmu *= inv_n; dlv *= inv_n; }
             a.d_heads[(long)b * a.ld_heads + l] = dmu;
             a.d_heads[(long)b * a.ld_heads + a.L + l] = dlv;
+            if (a.d_heads_lp) {
+                bf16* lp = (bf16*)a.d_heads_lp + (long)b * a.ld_heads_lp;
+                lp[l] = (bf16)dmu; lp[a.L + l] = (bf16)dlv;
+                if (l == 0) for (int e = 2 * a.L; e < a.ld_heads_lp; ++e) lp[e] = (bf16)0.f;       // pad columns
+            }
             if (a.d_table && sidx[u] >= 0) {
                 const long sx = sidx[u];
                 if (use_lds) { atomicAdd(&sT[sx * L2 + l], dmu); atomicAdd(&sT[sx * L2 + a.L + l], dlv); }
@@ -651,7 +656,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 15; }
+extern "C" int mmvae_abi_version(void) { return 16; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;

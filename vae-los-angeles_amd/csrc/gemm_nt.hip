@@ -386,8 +386,9 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
             if (a->epi_mask && (a->N % 16 || a->ld_epi_mask % 16 || ((uintptr_t)a->epi_mask & 15))) return MMVAE_ERR_ARG;
         }
         if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
-            // phase 2 (store d + statistics) on plain bf16 operands with at least two K steps: row-coalesced LDS epilogue (gemm_nt2.h)
-            if (g_bnbwd_stream && g_nt2_on && a->bn_phase == 2 && a->K > 64 && a->ldh % 4 == 0 && a->ldc % 4 == 0 &&
+            // phase 2 (store d + statistics) on plain bf16 operands: row-coalesced LDS epilogue (gemm_nt2.h); a single K step is fine here,
+            // this epilogue's kernel starts no DMA for the next tile before it is done
+            if (g_bnbwd_stream && g_nt2_on && a->bn_phase == 2 && a->ldh % 4 == 0 && a->ldc % 4 == 0 &&
                 (!a->epi_mask || (a->ld_epi_mask % 4 == 0 && ((uintptr_t)a->epi_mask & 3) == 0)) && ((uintptr_t)a->h & 7) == 0 && ((uintptr_t)a->c & 7) == 0) {
                 EpiBnBwdStream e{(bf16*)a->c, a->ldc, (const bf16*)a->h, a->ldh, a->epi_mask, a->ld_epi_mask,
                                  a->bn_scale, a->bn_shift, a->bn_mean, a->bn_rstd, a->epi_inv_keep, a->stat1, a->stat2};

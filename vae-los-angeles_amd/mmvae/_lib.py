@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -85,7 +85,7 @@ class FuseBwdArgs(C.Structure):
                 ("g_mu", vp), ("g_lv", vp), ("dz", vp), ("dz2", vp), ("dz3", vp), ("lddz", i64),
                 ("eps", vp), ("logvar", vp),
                 ("d_heads", vp), ("ld_heads", i64),
-                ("d_table", vp), ("site", vp), ("S", i32), ("table_copies", i32)]
+                ("d_table", vp), ("site", vp), ("S", i32), ("d_heads_lp", vp), ("ld_heads_lp", i64), ("table_copies", i32)]
 
 
 class LossArgs(C.Structure):

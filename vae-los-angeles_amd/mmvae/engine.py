@@ -229,7 +229,7 @@ class EncoderMLP:
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
-    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None, train=True):
+    def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None, train=True, d_heads_lp=None):
         """d_heads: [B][2L] fp32.  grads: dict param -> fp32 view (pre-zeroed, accumulated).
         train=False: the forward ran in eval mode (running statistics, no dropout) -- torch's
         batch_norm(training=False) backward: dy = gamma * rstd * d, no batch-statistics correction."""
@@ -243,7 +243,7 @@ class EncoderMLP:
         gb = grads[self.fc_mu.bias]
         tn(prec, d_heads, y, _span(gw, L2 * Kl).view(L2, Kl), _span(gb, L2), L2, Kl, q_prologue=pro, tag=f"{self.name}.heads.dW")
         # gradient entering the last hidden layer: dX GEMM of the heads (A = d_heads, W = heads^T)
-        src, src_wt, src_n, src_k = d_heads, self.pl_heads.wt, Kl, L2
+        src, src_wt, src_n, src_k = (d_heads_lp if d_heads_lp is not None else d_heads), self.pl_heads.wt, Kl, L2
         for i in reversed(range(len(self.linears))):
             lin, bn, pl = self.linears[i], self.bns[i], self.pl[i]
             h_in, pro_in, y, st, pro = saved[i]
@@ -672,11 +672,13 @@ class VAEGraph:
         n_mod = saved["n_mod"]
         d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
         d_table = extra[-1][:n_tab].view(L_.TABLE_COPIES, -1, 2 * Ld) if site is not None else None
-        ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, saved["eps"], saved["logvar"], d_heads, d_table, site)
+        # bf16 mode: a bf16 copy of d_heads for the heads' dX GEMMs (they round it on load anyway; plain bf16 A -> LDS-DMA kernel)
+        d_heads_lp = torch.empty(B, ceil_to(2 * Ld, 8), dtype=torch.bfloat16, device=dev) if prec == PREC_BF16 else None
+        ops.fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, saved["eps"], saved["logvar"], d_heads, d_table, site, d_heads_lp=d_heads_lp)
         if "enc_a" in saved:
-            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)], train=saved["train"])
+            self.enc_a.backward(prec, saved["enc_a"], d_heads, grads, tn, st_bwd[:len(wa)], train=saved["train"], d_heads_lp=d_heads_lp)
         if "enc_b" in saved:
-            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):], train=saved["train"])
+            self.enc_b.backward(prec, saved["enc_b"], d_heads, grads, tn, st_bwd[len(wa):], train=saved["train"], d_heads_lp=d_heads_lp)
         if site is not None:
             self.enc_c.backward(d_table, grads)
         flush_tiny("tiny_dW.heads")

@@ -367,13 +367,14 @@ def fuse_reparam_fwd(B, Ld, heads_a, heads_b, table, site, eps, mu, logvar, z):
         L.check(L.load().mmvae_fuse_reparam_fwd(C.byref(a), _stream()), "mmvae_fuse_reparam_fwd")
 
 
-def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_table, site):
+def fuse_reparam_bwd(B, Ld, n_mod, g_mu, g_lv, dzs, eps, logvar, d_heads, d_table, site, d_heads_lp=None):
     """dzs: 1..3 fp32 (B, Ld) tensors with one leading dimension (dL/dz of each decoder); they are summed.
     d_table: zeroed [S][2L] or [copies][S][2L] (workgroups spread their scatter-adds over the copies)."""
     dzs = list(dzs) + [None] * (3 - len(dzs))
     copies = d_table.shape[0] if (d_table is not None and d_table.dim() == 3) else 1
     a = L.FuseBwdArgs(B, Ld, n_mod, _p(g_mu), _p(g_lv), dzs[0].data_ptr(), _p(dzs[1]), _p(dzs[2]), _ld(dzs[0]), eps.data_ptr(), logvar.data_ptr(),
-                      d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[-2] if d_table is not None else 0, copies)
+                      d_heads.data_ptr(), _ld(d_heads), _p(d_table), _p(site), d_table.shape[-2] if d_table is not None else 0,
+                      _p(d_heads_lp), _ld(d_heads_lp) if d_heads_lp is not None else 0, copies)
     n_dz = sum(1 for d in dzs if d is not None)
     with probe_span("fuse_reparam_bwd", B * Ld * 4 * (n_dz + (g_mu is not None) + (g_lv is not None) + 2 + 2)):
         L.check(L.load().mmvae_fuse_reparam_bwd(C.byref(a), _stream()), "mmvae_fuse_reparam_bwd")
