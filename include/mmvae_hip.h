@@ -43,7 +43,7 @@ int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes bindi
  * 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32 at the scaled omics widths) is processed in row blocks of
  * at most half that threshold (2 GiB) inside the entry point; key 3 lowers it so that tests reach that path at moderate sizes;
  * key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off; key 5 = LDS-DMA form of the NT kernel for fp32 A
- * operands (gemm_nt2.h) on/off (default off: measured equal); key 6 = row-coalesced LDS form of the BatchNorm-backward dX epilogue on/off. */
+ * operands (gemm_nt2.h) on/off (default off: measured equal); key 6 / key 7 = row-coalesced LDS form of the BatchNorm-backward / ReLU-mask dX epilogue on/off. */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -65,6 +65,8 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
 /* ---------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( prologue(A)[M,K] x W[N,K]^T )          (gemm_nt.hip)
  *   W        prepared operand [ceil128(N)][ceil64(K)] in compute type, ldw % 64 == 0
+ *   A (bf16) rows are padded to a multiple of 8 elements and the pad columns must hold ZEROS (every producer in this library writes
+ *            them): the LDS-DMA kernels move whole 16-byte chunks and multiply the pads with the zero padding of W -- 0 x NaN bits is NaN
  *   h, masks are [M][ld] matrices: a kernel may READ a whole row of ld elements from a row's first element (tiles are loaded in
  *            full 128-byte lines).  For a column slice of a wider buffer that reaches past the slice's row end -- harmless inside the
  *            buffer, so the buffer's tail must extend 512 bytes beyond its last row (mmvae.engine pads the merged decoder stem)

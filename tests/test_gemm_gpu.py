@@ -437,3 +437,31 @@ def test_bn_bwd_epilogue_row_coalesced_form(M, N, K, with_mask):
     assert float((res[1][0][:, :N].double().cpu() - dref).abs().max()) <= _tol(K, float(dref.abs().max()), out_bf16=True)
     ref_st = torch.stack([dref.sum(0), (dref * xh).sum(0)])
     assert float((res[1][1].cpu() - ref_st).abs().max()) <= 3e-5 * np.sqrt(M) * float(ref_st.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 572), (333, 200, 128), (4100, 128, 782)])
+def test_relu_mask_epilogue_row_coalesced_form(M, N, K):
+    """ReLU-backward dX epilogue in the row-coalesced LDS form (mmvae_set_tuning key 7) against the accumulator-layout form: same
+    bits; output and saved activation as column slices of wider buffers (the merged decoder stem hands such slices over)."""
+    from mmvae import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, ops.ceil_to(K, 8), generator=g).bfloat16().to(DEV)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    pl = _prep(W.to(DEV), torch.zeros(N, device=DEV), PREC_BF16)
+    Np = ops.ceil_to(N, 8)
+    Hbig = torch.randn(M, Np + 64, generator=g).bfloat16().to(DEV)
+    H = Hbig[:, 32:32 + Np]
+    res = []
+    try:
+        for on in (0, 1):
+            lib.mmvae_set_tuning(7, on)
+            Cbig = torch.full((M, Np + 64), 5.0, dtype=torch.bfloat16, device=DEV)
+            C = Cbig[:, 16:16 + Np]
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, C, epilogue=ops.EPI_RELU_MASK, h=H)
+            res.append(Cbig)
+    finally:
+        lib.mmvae_set_tuning(7, 1)
+    assert torch.equal(res[0].view(torch.int16), res[1].view(torch.int16))          # incl. the untouched neighbours of the slice
+    ref = torch.where(H[:, :N].double().cpu() > 0, A[:, :K].double().cpu() @ _round(W, PREC_BF16).double().t(), torch.zeros(M, N, dtype=torch.float64))
+    assert float((res[1][:, 16:16 + N].double().cpu() - ref).abs().max()) <= _tol(K, float(ref.abs().max()), out_bf16=True)

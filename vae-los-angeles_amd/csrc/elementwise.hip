@@ -503,9 +503,13 @@ __global__ void loss_finalize_kernel(const double* sums, float beta, float gamma
 template <typename OT>
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(int M, int N, const float* g, long ldg, const float* p, long ldp,
                                                            OT* out, long ldo) {
-    const long total = (long)M * N;
+    // the pad columns of the output rows (up to the next multiple of 8) are written as zeros: the GEMM operand contract -- the LDS-DMA
+    // kernels multiply them with zero weights, and 0 x (uninitialised NaN bits) is NaN
+    const int Np = (int)min((long)((N + 7) & ~7), ldo);
+    const long total = (long)M * Np;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / N), c = (int)(i % N);
+        const int r = (int)(i / Np), c = (int)(i % Np);
+        if (c >= N) { out[(long)r * ldo + c] = from_f32<OT>(0.f); continue; }
         const float pv = p[(long)r * ldp + c];
         out[(long)r * ldo + c] = from_f32<OT>(g[(long)r * ldg + c] * pv * (1.f - pv));
     }

@@ -311,6 +311,7 @@ template <> struct IsPlainF32x4<SrcPlain<bf16, float, 4>> { static constexpr boo
 // of A + W a CU ingests per K step either way): off by default, kept as the A/B arm (mmvae_set_tuning key 5, MMVAE_NT2_F32=1)
 static int g_nt2_f32 = getenv("MMVAE_NT2_F32") ? 1 : 0;
 static int g_bnbwd_stream = getenv("MMVAE_NO_BNBWD_STREAM") ? 0 : 1;          // mmvae_set_tuning key 6
+static int g_relu_stream = getenv("MMVAE_NO_RELU_STREAM") ? 0 : 1;            // mmvae_set_tuning key 7
 template <typename T> struct IsPlainBf16 { static constexpr bool value = false; };
 template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool value = true; };
 
@@ -370,6 +371,12 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
         if (a->h == nullptr) return MMVAE_ERR_ARG;
         if ((a->c_dtype == MMVAE_BF16) != (sizeof(LP) == 2)) return MMVAE_ERR_DTYPE;
         if (sizeof(LP) == 2 && (a->ldc % 8 || a->ldh % 8 || ((uintptr_t)a->c & 15) || ((uintptr_t)a->h & 15))) return MMVAE_ERR_ARG;
+        if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
+            if (g_relu_stream && g_nt2_on && a->ldh % 4 == 0 && a->ldc % 4 == 0 && ((uintptr_t)a->h & 7) == 0 && ((uintptr_t)a->c & 7) == 0) {
+                EpiReluMaskStream e{(bf16*)a->c, a->ldc, (const bf16*)a->h, a->ldh};
+                return launch_nt2<EpiReluMaskStream, 2>(src.p, src.lda, a->w, a->ldw, a->M, a->N, a->K, e, st);
+            }
+        }
         EpiReluMask<LP, LP> e{(LP*)a->c, a->ldc, (const LP*)a->h, a->ldh, nullptr, 0, nullptr, nullptr};
         return launch_nt<CT>(src, a->w, a->ldw, a->M, a->N, a->K, e, st);
     }
@@ -470,6 +477,7 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     if (key == 4) { mm::tn_wide_enable(value); return 0; }
     if (key == 5) { mm::g_nt2_f32 = value; return 0; }
     if (key == 6) { mm::g_bnbwd_stream = value; return 0; }
+    if (key == 7) { mm::g_relu_stream = value; return 0; }
     return MMVAE_ERR_ARG;
 }
 

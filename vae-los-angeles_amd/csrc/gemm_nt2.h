@@ -111,6 +111,45 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
     }
 }
 
+// ReLU-mask dX epilogue in the row-coalesced form (EpiReluMaskStream): 8 bytes of the saved activation per thread and pass, one select
+// per element, 8-byte stores along rows.
+template <typename Epi, int WN>
+__device__ __forceinline__ void nt2_relumask_epilogue(unsigned char* smem, f32x4 (&acc)[4][4], const Epi& epi,
+                                                      int row0, int col0, int M, int N, int tid, int lane, int wr, int wc)
+{
+    static_assert(WN == 2, "128 x 128 tiles: the fp32 tile is exactly the 64 KB ring");
+    const int li = lane & 15, lg = lane >> 4;
+    const int c = tid & 31, r0 = tid >> 5;
+    const int colg = col0 + 4 * c;
+    const bf16* __restrict__ H = epi.H;
+    bf16* __restrict__ C = epi.C;
+    const int ch_ = min(colg, (int)epi.ldh - 4);
+    bf16x4 hv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hv[i] = *(const bf16x4*)(H + (long)min(row0 + r0 + 8 * i, M - 1) * epi.ldh + ch_);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wr * 64 + m * 16 + li, ch = 16 * wc + 4 * n + lg;
+            *(f32x4*)(smem + row * 512 + ((ch ^ (row & 7)) << 4)) = acc[m][n];
+        }
+    __syncthreads();
+    const int ccols = (int)min((long)((N + 7) & ~7), epi.ldc);
+    const unsigned char* src = smem + r0 * 512 + ((c ^ (r0 & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int grow = row0 + r0 + 8 * i;
+        const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)((colg + e < N && (float)hv[i][e] > 0.f) ? z[e] : 0.f);
+        if (grow < M && colg < ccols) *(bf16x4*)(C + (long)grow * epi.ldc + colg) = o;
+    }
+    __syncthreads();                                               // the ring may be refilled
+}
+
 // BatchNorm-backward dX epilogue in the same row-coalesced form (EpiBnBwdStream): thread (row r0 + 8 i, 4 columns) loads 8 bytes of
 // the saved pre-BN output y and 4 mask bytes per pass, computes d = acc * keep * (y*scale + shift > 0) and xhat, keeps its four
 // columns' partial sums of d and d*xhat in registers over its 16 rows (no butterfly), stores bf16 d; the 8 row groups are added
@@ -322,6 +361,7 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // more live registers across the last MFMAs spilled, and the co-resident workgroup covers the latency
         if constexpr (Epi::LDS_STREAM) {
             if constexpr (Epi::MODE == 2) nt2_bnbwd_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
+            else if constexpr (Epi::MODE == 3) nt2_relumask_epilogue<Epi, WN>(smem, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
             else nt2_loss_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
             if (Tn >= 0) issue(Tn, 0, g & 1);                       // the ring is free again (the epilogue ends in a barrier)
         } else {

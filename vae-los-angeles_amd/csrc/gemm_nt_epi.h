@@ -164,6 +164,20 @@ struct EpiBnBwdStream {
     }
 };
 
+// ReLU backward around a dX contraction (EpiReluMask: C = (h > 0) ? acc : 0) in the row-coalesced LDS form (gemm_nt2.h): bf16 h and C.
+struct EpiReluMaskStream {
+    static constexpr bool STATS = false;
+    static constexpr bool LDS_STREAM = true;
+    static constexpr int NEED = 0;
+    static constexpr int MODE = 3;
+    typedef float out_t; typedef float h_t;
+    bf16* C; long ldc; const bf16* H; long ldh;
+    struct Col { float b; };
+    static constexpr int NCOL = 0;
+    bool accumulate_requested() const { return false; }
+    __device__ __forceinline__ void fill(float*, int, int, int, int) const {}
+};
+
 // Column order of a wave's 64 output columns inside its 4 MFMA n-tiles.
 template <bool PAIR> struct EpiCols {
     static constexpr int G = PAIR ? 8 : 4;            // consecutive columns a lane owns per group
