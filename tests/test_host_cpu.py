@@ -69,6 +69,26 @@ def test_ctypes_structs_match_c_layout(tmp_path):
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
+def test_binding_constants_match_the_header(tmp_path):
+    """Enumerators and macros of include/mmvae_hip.h as gcc sees them == the constants of the ctypes binding."""
+    import subprocess
+    names = {"MMVAE_EPI_STORE": _lib.EPI_STORE, "MMVAE_EPI_RELU_MASK": _lib.EPI_RELU_MASK, "MMVAE_EPI_BN_BWD": _lib.EPI_BN_BWD,
+             "MMVAE_EPI_LOSS_MSE": _lib.EPI_LOSS_MSE, "MMVAE_EPI_LOSS_BCE_LOGIT": _lib.EPI_LOSS_BCE_LOGIT,
+             "MMVAE_CTR_COPIES": _lib.CTR_COPIES, "MMVAE_TN_GROUP_MAX": _lib.TN_GROUP_MAX, "MMVAE_TABLE_COPIES": _lib.TABLE_COPIES,
+             "MMVAE_PRO_NONE": _lib.PRO_NONE, "MMVAE_PRO_BN_RELU_DROP": _lib.PRO_BN_RELU_DROP, "MMVAE_PRO_BN_BWD_APPLY": _lib.PRO_BN_BWD_APPLY,
+             "MMVAE_F32": _lib.F32, "MMVAE_BF16": _lib.BF16, "MMVAE_PREC_F32": _lib.PREC_F32, "MMVAE_PREC_BF16": _lib.PREC_BF16}
+    lines = ['#include <stdio.h>', '#include "mmvae_hip.h"', "int main(void) {"]
+    lines += [f'printf("{n} %ld\\n", (long)({n}));' for n in names]
+    lines.append("return 0; }")
+    src = tmp_path / "consts.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "consts"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, v in names.items():
+        assert int(got[n]) == v, n
+
+
 def test_drop_in_surface_and_state_dict_abi():
     import src.models as M
     import src.utils as U
