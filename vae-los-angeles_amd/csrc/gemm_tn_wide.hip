@@ -1,21 +1,25 @@
 // Wide-tile TN GEMM for the LARGE weight gradients of the step (gfx950, bf16 MFMA):
 //     dW[N,K] += P[M,N]^T * Q[M,K],   db[N] += column sums of P
-// for the first encoder layers (P = BatchNorm-backward-corrected dY built from the bf16 d and y tensors, Q = the fp32 input
-// batch: EncoderB.L0.dW 512 x 572, EncoderA.L0.dW 128 x 782) and the last decoder layer (P = bf16 loss gradient, Q = bf16
-// hidden activation: DecoderB.L2.dW 572 x 512).  Reference op: the autograd mm of nn.Linear's backward behind
-// optimize_hyperparameters.py:112 (layers encoders.py:13,31 and decoders.py:28).
+// for the first encoder layers: P = BatchNorm-backward-corrected dY built from the bf16 d and y tensors, Q = the fp32 input batch
+// (EncoderB.L0.dW 512 x 572, EncoderA.L0.dW 128 x 782).  Reference op: the autograd mm of nn.Linear's backward behind
+// optimize_hyperparameters.py:112 (layers encoders.py:13,31).
 //
 // Why a second kernel next to gemm_tn.hip's 128 x 128 tiles.  With M = 65 536 batch rows and a 1 MB output, the batch is split
 // over all 256 CUs and every workgroup streams its rows of P and Q once PER OUTPUT TILE: 128 x 128 tiles re-ingest P five times
 // and Q four times for the 512 x 572 gradient (1.27 GB through the L2 -> CU path, which moves ~60 GB/s per CU: 83 us before any
 // arithmetic), and repeat the BatchNorm correction of P and the fp32 -> bf16 conversion of Q as often.  Here a workgroup of
-// 8 waves owns a 256 x 288 (or 128 x 448, 288 x 256) tile: 2 x 2 tiles for that gradient, P re-read twice and Q twice (0.57 GB),
+// 8 waves owns a 256 x 288 (or 128 x 448) tile: 2 x 2 tiles for that gradient, P re-read twice and Q twice (0.57 GB),
 // 36 MFMAs per wave and batch step on 13 transposed fragments.
 //
-// Layout: a batch step is 32 rows (one 16x16x32 MFMA reduction).  P and Q tiles sit row-major in LDS, rows padded to a multiple
-// of 256 bytes, each 256-byte panel (128 columns) with gemm_tn.hip's XOR swizzle of its 32-byte units, so the transposed
-// fragments come from ds_read_b64_tr_b16 without bank conflicts.  One register set, double-buffered LDS, one barrier per step.
-// Partial tiles of the batch splits go to the slab workspace and are summed by gemm_tn.hip's tn_reduce_kernel (fixed order).
+// Two forms.  gemm_tnw_dma_kernel (256 x 288 tiles, 16-byte aligned fp32 rows): raw tiles by LDS-DMA, everything else at fragment
+// time (below).  gemm_tnw_kernel (128 x 448 tiles; EncoderA.L0: fp32 rows only 8-byte aligned): global -> VGPR -> correction /
+// conversion -> LDS with one register set, double-buffered LDS, one barrier per step.  Plain bf16 x bf16 problems (the decoders'
+// gradients) were measured on these tiles too and stay with gemm_tn.hip's 128 x 128 LDS-DMA form (57-59 against 58 us, larger reduce).
+//
+// Layout: a batch step is 32 rows (one 16x16x32 MFMA reduction).  Tiles sit row-major in LDS, rows padded to a multiple of 256 bytes,
+// each 256-byte panel (128 columns) with gemm_tn.hip's XOR swizzle of its 32-byte units, so the transposed fragments come from
+// ds_read_b64_tr_b16 without bank conflicts.  Partial tiles of the batch splits go to the slab workspace and are summed by
+// gemm_tn.hip's tn_reduce_kernel (fixed order up to 128 splits).
 #include "common.h"
 #include "mmvae_hip.h"
 
