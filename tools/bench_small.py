@@ -35,3 +35,10 @@ buf = torch.empty(total, dtype=torch.uint8, device=dev); e2 = torch.empty(B, Ld,
 off = torch.zeros(16384, dtype=torch.int64, device=dev)
 print("noise  58.7 M mask bytes + 1.3 M normals    :", round(t(lambda: ops.noise(buf, e2, 0.9, 1234, 0, off, advance=True)), 1))
 print("noise  masks only                            :", round(t(lambda: ops.noise(buf, None, 0.9, 1234, 0, off, advance=True)), 1))
+rc, gc = torch.randn(B, S, device=dev), torch.empty(B, S, device=dev)
+mu_, lv_ = torch.randn(B, Ld, device=dev), torch.randn(B, Ld, device=dev)
+gm, gl = torch.empty_like(mu_), torch.empty_like(lv_)
+sums = torch.zeros(5, dtype=torch.float64, device=dev)
+print("vae_loss  class + KL terms                  :", round(t(lambda: ops.vae_loss(B, logits=rc, site=site, mu=mu_, logvar=lv_, sums=sums, g_c=gc, g_mu=gm, g_lv=gl)), 1))
+print("vae_loss  class term only                    :", round(t(lambda: ops.vae_loss(B, logits=rc, site=site, sums=sums, g_c=gc)), 1))
+print("vae_loss  KL term only                       :", round(t(lambda: ops.vae_loss(B, mu=mu_, logvar=lv_, sums=sums, g_mu=gm, g_lv=gl)), 1))

@@ -471,12 +471,23 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
         }
     }
     if (a.mu) {
+        // KL_U elements per thread are loaded before any is processed: the gradient stores may alias the next loads as far as the
+        // compiler knows, and one element per iteration made this a chain of dependent round trips (13 us for 21 MB)
+        constexpr int KL_U = 4;
         const long total = (long)a.B * a.L;
-        for (long i = tid0; i < total; i += stride) {
-            const float mu = a.mu[i], lv = a.logvar[i], ex = expf(lv);
-            s[3] += -0.5f * (1.f + lv - mu * mu - ex);
-            if (a.g_mu) a.g_mu[i] = a.beta * mu;
-            if (a.g_lv) a.g_lv[i] = -0.5f * a.beta * (1.f - ex);
+        for (long i0 = tid0; i0 < total; i0 += stride * KL_U) {
+            float mu[KL_U], lv[KL_U];
+#pragma unroll
+            for (int u = 0; u < KL_U; ++u) { const long i = min(i0 + u * stride, total - 1); mu[u] = a.mu[i]; lv[u] = a.logvar[i]; }
+#pragma unroll
+            for (int u = 0; u < KL_U; ++u) {
+                const long i = i0 + u * stride;
+                if (i >= total) break;
+                const float ex = expf(lv[u]);
+                s[3] += -0.5f * (1.f + lv[u] - mu[u] * mu[u] - ex);
+                if (a.g_mu) a.g_mu[i] = a.beta * mu[u];
+                if (a.g_lv) a.g_lv[i] = -0.5f * a.beta * (1.f - ex);
+            }
         }
     }
     __shared__ float red[4][5];
@@ -771,7 +782,10 @@ static int launch_loss(const mmvae_loss_args* a, hipStream_t st) {
     // inside the decoder GEMMs) the class / KL terms alone must still fill the chip (a row per thread, not four rows on 64 workgroups)
     const long work = (long)a->B * ((a->recon_a ? a->A / va : 0) + (a->recon_b ? a->D / vd : 0) + (a->logits ? 4 * a->S : 0) + (a->mu ? a->L : 0) + 1);
     static const int wg_cap = getenv("MMVAE_LOSS_WG") ? atoi(getenv("MMVAE_LOSS_WG")) * 256 : 1024;
-    const int grid = mm::grid_for(work, 256 * 4, wg_cap);
+    int grid = mm::grid_for(work, 256 * 4, wg_cap);
+    // class / KL terms alone (reconstruction terms inside the decoder GEMMs): every workgroup ends in f64 atomics on the same few
+    // addresses; with the row and element loops unrolled 512 workgroups are enough to cover the latency and halve that tail
+    if (!a->recon_a && !a->recon_b && grid > 512) grid = 512;
 #define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a)
     if (va == 4 && vd == 4) MM_LOSS(4, 4); else if (va == 4 && vd == 2) MM_LOSS(4, 2); else if (va == 4) MM_LOSS(4, 1);
     else if (va == 2 && vd == 4) MM_LOSS(2, 4); else if (va == 2 && vd == 2) MM_LOSS(2, 2); else if (va == 2) MM_LOSS(2, 1);
