@@ -109,7 +109,37 @@ def test_scaled_widths_at_batch_65536(prec):
         err = (got - want).abs().max().item() / scale
         report(f"scaled widths B=65536 prec={prec}: {enc} first BatchNorm batch mean vs mean(x) W^T + b: {err:.2e} of scale")
         assert err <= (1e-4 if prec == "fp32" else 2e-3)
-    del outs, grads
+    del outs
+
+    # the fused training step (reconstruction losses inside the decoders' last GEMMs: 5.2 / 7.1 GB fp32 targets behind 64-bit row offsets)
+    # against the public call sequence above: same Philox draws, same running statistics
+    from mmvae import functional as F_
+    dev = torch.device(DEV, torch.cuda.current_device())
+    def fused_or_not(fuse):
+        engine.GLOBAL_NOISE.offset_tensor(dev).zero_()
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        g = model._graph()
+        g.fused_recon = [a, b, None] if fuse else None
+        try:
+            ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+        finally:
+            g.fused_recon = None
+        total, out5 = F_.fused_loss({"a": (ra, a), "b": (rb, b), "c": (rc, site), "kl": (mu, lv)}, 1e-3, 1.0)
+        for p in model.parameters():
+            p.grad = None
+        total.backward()
+        torch.cuda.synchronize()
+        return np.array(F_.read_losses(out5)), {k: model.get_parameter(k).grad.clone() for k in ("decoder_a.fc.2.weight", "decoder_b.fc.4.weight", "encoder_b.fc.0.weight")}
+    l0, g0 = fused_or_not(False)
+    l1, g1 = fused_or_not(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for k in g0:
+        e = float((g0[k] - g1[k]).norm() / g0[k].norm())
+        assert e <= 1e-4, (k, e)
+    report(f"scaled widths B=65536 prec={prec}: fused step vs public call sequence: loss rel {np.abs(l1 / l0 - 1).max():.1e}")
+    del grads, g0, g1
 
     # eval mode: full batch (row blocks) == sum over quarters (single launches)
     model.eval()
