@@ -465,3 +465,30 @@ def test_relu_mask_epilogue_row_coalesced_form(M, N, K):
     assert torch.equal(res[0].view(torch.int16), res[1].view(torch.int16))          # incl. the untouched neighbours of the slice
     ref = torch.where(H[:, :N].double().cpu() > 0, A[:, :K].double().cpu() @ _round(W, PREC_BF16).double().t(), torch.zeros(M, N, dtype=torch.float64))
     assert float((res[1][:, 16:16 + N].double().cpu() - ref).abs().max()) <= _tol(K, float(ref.abs().max()), out_bf16=True)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 2000), (8192, 256, 12000), (16384, 128, 6000)])
+def test_tn_wide_tiles_plain_p_fp32_q(M, N, K):
+    """Wide-tile dW kernel with a plain bf16 P and an fp32 Q (first encoder layers at very wide inputs, where the engine applies the
+    BatchNorm correction in a pass of its own): LDS-DMA forms of both tile shapes, incl. the linear block map used below 8 batch
+    splits (K = 12000 -> 42 tiles, 6 splits), against the 128 x 128 kernel (mmvae_set_tuning key 4) and float64."""
+    from mmvae import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + K)
+    P = torch.randn(M, N, generator=g).bfloat16()
+    Q = torch.randn(M, K, generator=g)
+    ref, refb = P.double().t() @ _round(Q, PREC_BF16).double(), P.double().sum(0)
+    slab = torch.empty(1 << 25, device=DEV)
+    Pd, Qd = P.to(DEV), Q.to(DEV)
+    res = []
+    try:
+        for on in (1, 0):
+            assert lib.mmvae_set_tuning(4, on) == 0
+            dw = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV)
+            ops.gemm_tn(PREC_BF16, Pd, Qd, dw, db, N, K, slab=slab)
+            res.append((dw.cpu().double(), db.cpu().double()))
+    finally:
+        lib.mmvae_set_tuning(4, 1)
+    for dw, db in res:
+        assert float((dw - ref).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
+        assert float((db - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4

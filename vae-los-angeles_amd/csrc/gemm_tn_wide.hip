@@ -29,7 +29,7 @@ struct TnwArgs {
     const bf16* p; unsigned ldp; const bf16* py; unsigned ldpy;
     const float* mean; const float* rstd; const float* coef;
     const void* q; unsigned ldq;
-    int M, N, K, ntk, ntiles, nsplit, rps;
+    int M, N, K, ntk, ntiles, nsplit, rps, linear;
     float* slab; float* db;
 };
 
@@ -85,9 +85,9 @@ void gemm_tnw_kernel(const TnwArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* aux = (float*)(smem + 2 * C::BUF);            // [4][NT]: mean, c0, c0 c2 rstd, c0 c1 of this tile's P columns
     const int L = (int)blockIdx.x;
-    const int slot = L >> 3;
-    const int tile = slot % a.ntiles;
-    const int zz = (slot / a.ntiles) * 8 + (L & 7);       // all tiles of a batch split on one XCD: P / Q rows shared in its L2
+    int tile, zz;
+    if (a.linear) { tile = L % a.ntiles; zz = L / a.ntiles; }     // fewer than 8 batch splits (very wide outputs): every XCD gets tiles
+    else { const int slot = L >> 3; tile = slot % a.ntiles; zz = (slot / a.ntiles) * 8 + (L & 7); }      // all tiles of a batch split on one XCD: P / Q rows shared in its L2
     if (zz >= a.nsplit) return;
     const int tn = tile / a.ntk, tk = tile % a.ntk;
     const int n0 = tn * C::NT, k0 = tk * C::KT;
@@ -289,9 +289,9 @@ void gemm_tnw_dma_kernel(const TnwArgs a)
     typedef __attribute__((address_space(1))) const void gbl_void;
 
     const int L = (int)blockIdx.x;
-    const int slot = L >> 3;
-    const int tile = slot % a.ntiles;
-    const int zz = (slot / a.ntiles) * 8 + (L & 7);
+    int tile, zz;
+    if (a.linear) { tile = L % a.ntiles; zz = L / a.ntiles; }
+    else { const int slot = L >> 3; tile = slot % a.ntiles; zz = (slot / a.ntiles) * 8 + (L & 7); }
     if (zz >= a.nsplit) return;
     const int tn = tile / a.ntk, tk = tile % a.ntk;
     const int n0 = tn * C::NT, k0 = tk * C::KT;
@@ -504,7 +504,7 @@ static int tnw_dma_launch(TnwArgs& w, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    const int grid = ((w.nsplit + 7) / 8) * 8 * w.ntiles;
+    const int grid = w.linear ? w.nsplit * w.ntiles : ((w.nsplit + 7) / 8) * 8 * w.ntiles;
     hipLaunchKernelGGL((gemm_tnw_dma_kernel<C, PMODE, QT, NSTAGE>), dim3(grid), dim3(512), LDS, st, w);
     MM_CHECK_LAUNCH();
     return 0;
@@ -521,7 +521,7 @@ static int tnw_launch(TnwArgs& w, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    const int grid = ((w.nsplit + 7) / 8) * 8 * w.ntiles;
+    const int grid = w.linear ? w.nsplit * w.ntiles : ((w.nsplit + 7) / 8) * 8 * w.ntiles;
     hipLaunchKernelGGL((gemm_tnw_kernel<C, PMODE, QT, QVEC>), dim3(grid), dim3(512), C::LDS, st, w);
     MM_CHECK_LAUNCH();
     return 0;
@@ -545,32 +545,37 @@ int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out)
     else if (a->ldq % 4 == 0 && a->K % 4 == 0 && ((uintptr_t)a->q & 15) == 0) qkind = 4;
     else if (a->ldq % 2 == 0 && a->K % 2 == 0 && ((uintptr_t)a->q & 7) == 0) qkind = 2;
     else return NA;
-    // instantiated combination: BatchNorm-corrected bf16 P with an fp32 Q (the first encoder layers).  Plain bf16 x bf16 problems
-    // (last decoder layers) were measured on this kernel too (3-stage ring): 57-59 us against 58 us of gemm_tn.hip's 128 x 128
-    // DMA form with two workgroups per CU, plus a larger slab reduce -- they stay there.
-    if (!pmode || qkind == 0) return NA;
+    // instantiated combinations: an fp32 Q (the input batch of the first encoder layers) with a BatchNorm-corrected bf16 P (the bench
+    // widths) or a plain bf16 P (very wide inputs, where the engine applies the correction in a pass of its own: hundreds of K tiles would
+    // each redo it).  Plain bf16 x bf16 problems (last decoder layers) were measured on this kernel too (3-stage ring): 57-59 us against
+    // 58 us of gemm_tn.hip's 128 x 128 DMA form with two workgroups per CU, plus a larger slab reduce -- they stay there.
+    if (qkind == 0) return NA;
+    if (!pmode && (qkind != 4 || a->M % 32)) return NA;   // plain P: LDS-DMA forms only
     auto padded = [&](int nt_, int kt_) { return (long)((a->N + nt_ - 1) / nt_ * nt_) * ((a->K + kt_ - 1) / kt_ * kt_); };
     const int cfg = (a->N <= 128 || padded(CfgB::NT, CfgB::KT) < padded(CfgA::NT, CfgA::KT)) ? 1 : 0;       // least padded output
     // 256 x 288 tiles run the LDS-DMA form: whole 32-row steps, 16-byte aligned fp32 rows, d and y with one row stride
-    if (cfg == 0 && (qkind != 4 || a->M % 32 || a->ldp != a->ld_py)) return NA;
+    if (pmode && cfg == 0 && (qkind != 4 || a->M % 32 || a->ldp != a->ld_py)) return NA;
     const int NT = cfg == 0 ? CfgA::NT : CfgB::NT, KT = cfg == 0 ? CfgA::KT : CfgB::KT;
     TnwArgs w;
     w.ntk = (a->K + KT - 1) / KT;
     w.ntiles = w.ntk * ((a->N + NT - 1) / NT);
-    if (w.ntiles > 32) return NA;                          // many tiles: little batch split left, the 128 x 128 kernel's case
-    int nsplit = (256 / w.ntiles) & ~7;                    // one workgroup per CU, whole XCD rounds
+    if (w.ntiles > (pmode ? 32 : 4096)) return NA;         // corrected P: every K tile redoes the correction -- the 128 x 128 kernel's case
+    int nsplit = 256 / w.ntiles;                           // one workgroup per CU
+    if (nsplit >= 8) nsplit &= ~7;                         // whole XCD rounds
     const int max_split = (a->M + 4 * 32 - 1) / (4 * 32);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     int rps = (a->M + nsplit - 1) / nsplit;
     rps = (rps + 31) / 32 * 32;
     nsplit = (a->M + rps - 1) / rps;
-    if ((long)nsplit * a->N * a->K > a->slab_elems || nsplit < 2) return NA;
-    w.nsplit = nsplit; w.rps = rps;
+    if ((long)nsplit * a->N * a->K > a->slab_elems) return NA;
+    if (pmode && nsplit < 2) return NA;
+    w.nsplit = nsplit; w.rps = rps; w.linear = nsplit < 8 ? 1 : 0;
     w.p = (const bf16*)a->p; w.ldp = (unsigned)a->ldp; w.py = (const bf16*)a->p_y; w.ldpy = (unsigned)a->ld_py;
     w.mean = a->p_mean; w.rstd = a->p_rstd; w.coef = a->p_coef;
     w.q = a->q; w.ldq = (unsigned)a->ldq; w.M = a->M; w.N = a->N; w.K = a->K; w.slab = a->slab; w.db = a->db;
     *nsplit_out = nsplit;
+    if (!pmode) return cfg == 0 ? tnw_dma_launch<CfgA, 0, float, 3>(w, st) : tnw_dma_launch<CfgB, 0, float, 2>(w, st);
     if (cfg == 0) return tnw_dma_launch<CfgA, 1, float, 2>(w, st);
     // 128 x 448 tiles (EncoderA.L0: K = 782, fp32 rows only 8-byte aligned -- 16-byte LDS-DMA pieces from such rows delivered wrong
     // data): the register form

@@ -262,7 +262,9 @@ class EncoderMLP:
             else:
                 ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
                 ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
-                if i == 0 and _FUSE_BN_APPLY:
+                # (not for very wide inputs -- the scaled omics widths: the dW GEMM then has hundreds of K tiles and every one of them
+                # would redo the correction of its P rows; one pass over d is cheaper)
+                if i == 0 and _FUSE_BN_APPLY and K <= 4096:
                     # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
                     tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
                        p_prologue=(y, st.mean, st.rstd, coef), tag=f"{self.name}.L{i}.dW")
