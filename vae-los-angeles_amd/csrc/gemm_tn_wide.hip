@@ -11,8 +11,8 @@
 // 8 waves owns a 256 x 288 (or 128 x 448) tile: 2 x 2 tiles for that gradient, P re-read twice and Q twice (0.57 GB),
 // 36 MFMAs per wave and batch step on 13 transposed fragments.
 //
-// Two forms.  gemm_tnw_dma_kernel (256 x 288 tiles, 16-byte aligned fp32 rows): raw tiles by LDS-DMA, everything else at fragment
-// time (below).  gemm_tnw_kernel (128 x 448 tiles; EncoderA.L0: fp32 rows only 8-byte aligned): global -> VGPR -> correction /
+// Two forms.  gemm_tnw_dma_kernel (256 x 288 tiles, 16-byte aligned fp32 rows; also 128 x 448 with a plain bf16 P -- very wide inputs,
+// where the BatchNorm correction runs as a pass of its own): raw tiles by LDS-DMA, everything else at fragment time (below).  gemm_tnw_kernel (128 x 448 tiles; EncoderA.L0: fp32 rows only 8-byte aligned): global -> VGPR -> correction /
 // conversion -> LDS with one register set, double-buffered LDS, one barrier per step.  Plain bf16 x bf16 problems (the decoders'
 // gradients) were measured on these tiles too and stay with gemm_tn.hip's 128 x 128 LDS-DMA form (57-59 against 58 us, larger reduce).
 //
