@@ -492,3 +492,31 @@ def test_tn_wide_tiles_plain_p_fp32_q(M, N, K):
     for dw, db in res:
         assert float((dw - ref).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
         assert float((db - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4
+
+
+def test_tn_wide_tiles_bf16_operands_large_output():
+    """bf16 x bf16 dW with a very large output (the decoders' last layers at the scaled omics widths, N K >= 4 M elements) runs the
+    wide-tile LDS-DMA kernel (3-stage ring, linear block map): against the 128 x 128 kernel (mmvae_set_tuning key 4) and float64;
+    N and K tails."""
+    from mmvae import _lib
+    lib = _lib.load()
+    M, N, K = 8192, 4100, 1100
+    g = torch.Generator().manual_seed(77)
+    P = torch.zeros(M, ops.ceil_to(N, 8), dtype=torch.bfloat16); P[:, :N] = torch.randn(M, N, generator=g).bfloat16()
+    Q = torch.zeros(M, ops.ceil_to(K, 8), dtype=torch.bfloat16); Q[:, :K] = torch.randn(M, K, generator=g).bfloat16()
+    ref, refb = P[:, :N].double().t() @ Q[:, :K].double(), P[:, :N].double().sum(0)
+    slab = torch.empty(1 << 25, device=DEV)
+    Pd, Qd = P.to(DEV), Q.to(DEV)
+    res = []
+    try:
+        for on in (1, 0):
+            assert lib.mmvae_set_tuning(4, on) == 0
+            dw = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV)
+            ops.gemm_tn(PREC_BF16, Pd, Qd, dw, db, N, K, slab=slab)
+            res.append((dw.cpu().double(), db.cpu().double()))
+    finally:
+        lib.mmvae_set_tuning(4, 1)
+    for dw, db in res:
+        assert float((dw - ref).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
+        assert float((db - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())

@@ -302,7 +302,9 @@ long g_split_bytes = 1L << 32;          // operands of at least this many bytes 
 
 static inline bool nt_wide_ok(int M, int N) {
     static const bool off = getenv("MMVAE_NO_WIDE_TILES") != nullptr;      // A/B switch
-    return !off && N % 256 == 0 && M >= g_wide_min_m;       // the prepared W has ceil128(N) rows: whole 256-column tiles only
+    // the prepared W has ceil128(N) rows: whole 256-column tiles only; one 8-wave workgroup per CU: at least 256 tiles (M >= 32768 at
+    // N = 256; a 16 384-row block of a 512-wide layer qualifies too)
+    return !off && N % 256 == 0 && ((long)M * (N / 256) >= (long)g_wide_min_m || M >= g_wide_min_m);
 }
 
 template <typename T> struct IsPlainF32x4 { static constexpr bool value = false; };
@@ -494,8 +496,12 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     long row_bytes = a_row > (long)a->ld_pro_mask ? a_row : (long)a->ld_pro_mask;
     if ((long)a->M * row_bytes >= mm::g_split_bytes) {
         long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
-        if (rows >= 256) rows &= ~255L;
         if (rows <= 0) return MMVAE_ERR_ARG;
+        const long nblk = (a->M + rows - 1) / rows;         // equal blocks (65 536 rows -> 4 x 16 384, not 3 x 19 712 + 6 400: a short
+        long even = (a->M + nblk - 1) / nblk;               // last block falls below the sizes the wide-tile kernels take)
+        if (even >= 256) even = (even + 255) & ~255L;
+        if (even <= rows) rows = even;
+        else if (rows >= 256) rows &= ~255L;
         for (long r0 = 0; r0 < a->M; r0 += rows) {
             mmvae_gemm_nt_args s = *a;
             s.M = (int32_t)((a->M - r0 < rows) ? a->M - r0 : rows);

@@ -664,8 +664,12 @@ extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if ((long)a->ld_pro_mask > row_bytes) row_bytes = a->ld_pro_mask;
     if ((long)a->M * row_bytes >= mm::g_split_bytes) {
         long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
-        if (rows >= 256) rows &= ~255L;
         if (rows <= 0) return MMVAE_ERR_ARG;
+        const long nblk = (a->M + rows - 1) / rows;         // equal blocks (see mmvae_gemm_nt)
+        long even = (a->M + nblk - 1) / nblk;
+        if (even >= 256) even = (even + 255) & ~255L;
+        if (even <= rows) rows = even;
+        else if (rows >= 256) rows &= ~255L;
         for (long r0 = 0; r0 < a->M; r0 += rows) {
             mmvae_gemm_tn_args s = *a;
             s.M = (int32_t)((a->M - r0 < rows) ? a->M - r0 : rows);

@@ -549,10 +549,13 @@ int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out)
     // widths) or a plain bf16 P (very wide inputs, where the engine applies the correction in a pass of its own: hundreds of K tiles would
     // each redo it).  Plain bf16 x bf16 problems (last decoder layers) were measured on this kernel too (3-stage ring): 57-59 us against
     // 58 us of gemm_tn.hip's 128 x 128 DMA form with two workgroups per CU, plus a larger slab reduce -- they stay there.
-    if (qkind == 0) return NA;
-    if (!pmode && (qkind != 4 || a->M % 32)) return NA;   // plain P: LDS-DMA forms only
+    if (qkind == 0) {
+        // bf16 x bf16 with a very large output (the decoders' last layers at the scaled widths: 27 000 x 512): 128 x 128 tiles re-ingest
+        // P four times and Q 211 times; at the bench widths gemm_tn.hip's form with two workgroups per CU is as fast (above)
+        if (pmode || a->M % 32 || (long)a->N * a->K < (4L << 20)) return NA;
+    } else if (!pmode && (qkind != 4 || a->M % 32)) return NA;   // plain P: LDS-DMA forms only
     auto padded = [&](int nt_, int kt_) { return (long)((a->N + nt_ - 1) / nt_ * nt_) * ((a->K + kt_ - 1) / kt_ * kt_); };
-    const int cfg = (a->N <= 128 || padded(CfgB::NT, CfgB::KT) < padded(CfgA::NT, CfgA::KT)) ? 1 : 0;       // least padded output
+    const int cfg = qkind == 0 ? 0 : (a->N <= 128 || padded(CfgB::NT, CfgB::KT) < padded(CfgA::NT, CfgA::KT)) ? 1 : 0;       // least padded output
     // 256 x 288 tiles run the LDS-DMA form: whole 32-row steps, 16-byte aligned fp32 rows, d and y with one row stride
     if (pmode && cfg == 0 && (qkind != 4 || a->M % 32 || a->ldp != a->ld_py)) return NA;
     const int NT = cfg == 0 ? CfgA::NT : CfgB::NT, KT = cfg == 0 ? CfgA::KT : CfgB::KT;
@@ -575,6 +578,7 @@ int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out)
     w.mean = a->p_mean; w.rstd = a->p_rstd; w.coef = a->p_coef;
     w.q = a->q; w.ldq = (unsigned)a->ldq; w.M = a->M; w.N = a->N; w.K = a->K; w.slab = a->slab; w.db = a->db;
     *nsplit_out = nsplit;
+    if (qkind == 0) return tnw_dma_launch<CfgA, 0, bf16, 3>(w, st);
     if (!pmode) return cfg == 0 ? tnw_dma_launch<CfgA, 0, float, 3>(w, st) : tnw_dma_launch<CfgB, 0, float, 2>(w, st);
     if (cfg == 0) return tnw_dma_launch<CfgA, 1, float, 2>(w, st);
     // 128 x 448 tiles (EncoderA.L0: K = 782, fp32 rows only 8-byte aligned -- 16-byte LDS-DMA pieces from such rows delivered wrong
