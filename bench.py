@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MultiModalVAE training hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1 directly
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without WORLD_SIZE in the environment: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -108,6 +108,40 @@ def cpu_baseline(B, steps):
                        f"same synthetic workload; {dt * 1e3:.0f} ms/step; `points`: the same step at batch 32 (100 steps) and 4096 (10 steps)")
 
 
+def spawn_ranks(n):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line), as
+    `python -m torch.distributed.run --nproc-per-node n` would start them; rank 0's stdout (the ONE JSON line) is ours.  Returns the
+    exit status: non-zero as soon as any rank fails (the others are then terminated -- they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return status
+
+
 def load_expectations():
     try:
         return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_expect.json")))
@@ -129,12 +163,14 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the GPU yet
+        # (torch is imported, no HIP call was made) and never will: it only waits for its children.
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")

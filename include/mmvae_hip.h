@@ -230,7 +230,8 @@ int mmvae_fuse_reparam_bwd(const mmvae_fuse_bwd_args* args, void* stream);
  *   sums[2] += sum_i w[site_i] * nll_i                          (losses.py:39)
  *   sums[3] += -0.5 * sum(1 + lv - mu^2 - exp(lv))              (losses.py:42)
  *   sums[4] += number of labels outside [0, S)  (torch's cross_entropy device-asserts on them; here such a row is
- *              computed as class 0 and COUNTED: the host wrapper raises when the count it reads back is not 0)
+ *              computed as class 0 and COUNTED: the host wrapper raises when the count it reads back is not 0).  A label of -100
+ *              is F.cross_entropy's default ignore_index: that row adds no loss and gets a zero gradient, and is not counted
  * `sums` is double[5], zeroed by the caller; mmvae_loss_finalize turns it into the tuple of losses.py:44,46 (a last-block
  * finalisation inside the kernel was measured: ~1000 tickets on one address + the fences cost 50 us against a 5 us launch).
  * Gradients of total = s0+s1+gamma*s2+beta*s3:
@@ -284,7 +285,8 @@ int mmvae_counter_add(uint64_t* counter_dev, uint64_t inc, void* stream);      /
 
 /* ---------------------------------------------------------------------------------------------
  * Minibatch assembly from a device-resident dataset: dst_t[i][:] = src_t[idx[i]][:], i < rows, for up to MMVAE_GATHER_MAX
- * row-major tensors sharing one int64 index vector (rows / strides in BYTES, multiples of 8).  Indices outside
+ * row-major tensors sharing one int64 index vector (rows / strides in BYTES, multiples of 4; 8-byte words are moved when everything
+ * is a multiple of 8).  Indices outside
  * [0, src_rows) are clamped.  Replaces: MultiModalDataset.__getitem__ + the DataLoader's default collate
  * (src/data/dataset.py:28-39, optimize_hyperparameters.py:55-65) -- one Python call and one torch.tensor() per SAMPLE.
  * ------------------------------------------------------------------------------------------- */

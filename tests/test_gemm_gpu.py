@@ -520,3 +520,52 @@ def test_tn_wide_tiles_bf16_operands_large_output():
         assert float((dw - ref).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
         assert float((db - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
+
+
+def _set_tuning(key, value):
+    from mmvae import _lib
+    _lib.check(_lib.load().mmvae_set_tuning(key, value), "mmvae_set_tuning")
+
+
+@pytest.mark.parametrize("M,N,K,lda,stats,act", [
+    (4480, 512, 572, 572, True, ops.ACT_NONE),      # EncoderB.L0 shape: 16-byte rows, 128 x 256 tiles, row tiles padded to a multiple of 8
+    (2048, 128, 782, 782, True, ops.ACT_NONE),      # EncoderA.L0 shape: 8-byte rows (16-byte loads at 8-byte alignment), K % 4 == 2: rotated tail piece
+    (12288, 384, 200, 201, True, ops.ACT_RELU),     # odd leading dimension (4-byte aligned rows); 3 column tiles: a workgroup changes column tile
+    (1024, 256, 130, 132, False, ops.ACT_NONE),     # K % 64 != 0 and K % 4 != 0 at 16-byte rows; no statistics
+    (640, 128, 97, 97, True, ops.ACT_SIGMOID),      # K % 4 == 1
+    (2056, 128, 782, 782, True, ops.ACT_NONE),      # a partial row tile: not taken by the wave-specialised kernel (both runs use the tile kernels)
+])
+def test_ntp_matches_tile_kernels(M, N, K, lda, stats, act):
+    """The wave-specialised NT kernel (gemm_ntp.h: producer / consumer waves, persistent) against the tile kernels it replaces on the
+    forward first layers: the same MFMA order over K -> bit-identical bf16 outputs; column statistics to fp32 summation order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    Af = torch.randn(M, lda, generator=g).to(DEV)
+    A = Af[:, :K]
+    W = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pl = _prep(W, b, PREC_BF16)
+    res = {}
+    try:
+        _set_tuning(9, 256)
+        for on in (0, 1):
+            _set_tuning(8, on)
+            out = torch.full((M, ops.ceil_to(N, 8)), 7.0, dtype=torch.bfloat16, device=DEV)
+            st = torch.zeros(2, N, dtype=torch.float64, device=DEV) if stats else None
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, act=act, stats=st)
+            torch.cuda.synchronize()
+            res[on] = (out.clone(), None if st is None else st.clone())
+    finally:
+        _set_tuning(8, 1); _set_tuning(9, 16384)
+    ref = A.to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t() + b.double()
+    if act == ops.ACT_RELU:
+        ref = ref.clamp_min(0)
+    elif act == ops.ACT_SIGMOID:
+        ref = torch.sigmoid(ref)
+    got = res[1][0][:, :N].double()
+    assert float((got - ref).abs().max()) <= _tol(K, float(ref.abs().max()), True)
+    assert torch.equal(res[0][0][:, :N], res[1][0][:, :N])
+    assert torch.all((res[1][0][:, N:].float() == 7.0) | (res[1][0][:, N:].float() == 0.0))
+    if stats:
+        np.testing.assert_allclose(res[1][1].cpu(), res[0][1].cpu(), rtol=2e-6, atol=1e-3)
+        np.testing.assert_allclose(res[1][1][0].cpu(), got.sum(0).cpu(), rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(res[1][1][1].cpu(), (got ** 2).sum(0).cpu(), rtol=1e-5, atol=1e-2)

@@ -79,9 +79,12 @@ template <> struct VLoad<bf16, 8> { static __device__ __forceinline__ void ld(co
 // behind the issue or in front of the next one -- a ring deeper than two slots then buys nothing (seen in the ISA of
 // gemm_tn_wide.hip and gemm_nt3.h).  Issued from assembly the transfers are invisible to that pass; the kernel's own counted waits
 // order them (vmcnt counts them in issue order like any other vector-memory operation).  m0 is written: kernels that use this
-// helper must not use the builtin form as well.
+// helper must not use the builtin form as well; the compiler's own value of m0 (it reserves the register and knows nothing of this
+// write: a clobber entry for it is only warned about) is saved and restored inside the statement.
 __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(g) : "memory");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(g) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;

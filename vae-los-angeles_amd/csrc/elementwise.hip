@@ -444,10 +444,11 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
                 long y = ys[u];
-                const bool bad = y < 0 || y >= a.S;
-                if (bad) y = 0;
+                const bool ign = y == -100;                  // F.cross_entropy's default ignore_index (losses.py:39): no loss, no gradient
+                const bool bad = !ign && (y < 0 || y >= a.S);
+                if (bad || ign) y = 0;
                 const float xy = __shfl(x, (lane_ & 32) + (int)y, 64);
-                const float w = (rv && a.class_weights) ? a.class_weights[y] : 1.f;
+                const float w = ign ? 0.f : ((rv && a.class_weights) ? a.class_weights[y] : 1.f);
                 if (sub == 0 && rv) { s[2] += w * (m + logf(se) - xy); if (bad) n_bad += 1.f; }
                 if (a.g_c && ev) a.g_c[r * a.ld_gc + sub] = a.gamma * w * (e / se - (sub == (int)y ? 1.f : 0.f));
             }
@@ -456,13 +457,15 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
         for (long r = tid0; r < a.B; r += stride) {
             const float* lg = a.logits + r * a.ld_logits;
             long y = a.site[r];
+            const bool ign = y == -100;                      // ignore_index, as above
+            if (ign) y = 0;
             if (y < 0 || y >= a.S) { y = 0; n_bad += 1.f; }          // torch device-asserts; counted in sums[4] / out[4], see mmvae_hip.h
             float m = -INFINITY;
             for (int j = 0; j < a.S; ++j) m = fmaxf(m, lg[j]);
             float se = 0.f;
             for (int j = 0; j < a.S; ++j) se += expf(lg[j] - m);
             const float lse = m + logf(se);
-            const float w = a.class_weights ? a.class_weights[y] : 1.f;
+            const float w = ign ? 0.f : (a.class_weights ? a.class_weights[y] : 1.f);
             s[2] += w * (lse - lg[y]);
             if (a.g_c) {
                 float* g = a.g_c + r * a.ld_gc;
@@ -605,7 +608,8 @@ __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
 
 // ------------------------------------------------------------------------------------------
 // minibatch assembly: out_t[i][:] = src_t[idx[i]][:] for up to MMVAE_GATHER_MAX row-major tensors that share the index vector
-// (the RNA matrix, the DNA matrix and the site labels of one shuffled minibatch).  One wave per (tensor, row), 8-byte words.
+// (the RNA matrix, the DNA matrix and the site labels of one shuffled minibatch).  One wave per (tensor, row), 8-byte words (4-byte
+// words when a width or address is only 4-byte aligned).
 // ------------------------------------------------------------------------------------------
 struct GatherBatch { mmvae_gather_item it[MMVAE_GATHER_MAX]; int n; };
 __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherBatch b, const int64_t* __restrict__ idx, int rows, long src_rows) {
@@ -616,10 +620,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherBatch b, c
         const mmvae_gather_item it = b.it[t];
         long r = idx[i];
         r = r < 0 ? 0 : (r >= src_rows ? src_rows - 1 : r);            // memory-safe on a bad index (torch would device-assert)
-        const uint2* s = (const uint2*)((const char*)it.src + r * it.src_row_stride);
-        uint2* d = (uint2*)((char*)it.dst + (long)i * it.dst_row_stride);
-        const int words = it.row_bytes >> 3;
-        for (int k = lane; k < words; k += 64) d[k] = s[k];
+        const char* sp = (const char*)it.src + r * it.src_row_stride;
+        char* dp = (char*)it.dst + (long)i * it.dst_row_stride;
+        if (((it.row_bytes | it.src_row_stride | it.dst_row_stride | (long)(uintptr_t)it.src | (long)(uintptr_t)it.dst) & 7) == 0) {      // uniform per item
+            const uint2* s = (const uint2*)sp; uint2* d = (uint2*)dp;
+            for (int k = lane; k < (it.row_bytes >> 3); k += 64) d[k] = s[k];
+        } else {                                                       // fp32 rows of an odd width (INPUT_DIM_* overrides): 4-byte words
+            const uint32_t* s = (const uint32_t*)sp; uint32_t* d = (uint32_t*)dp;
+            for (int k = lane; k < (it.row_bytes >> 2); k += 64) d[k] = s[k];
+        }
     }
 }
 
@@ -883,8 +892,8 @@ extern "C" int mmvae_gather_rows(const mmvae_gather_item* items_host, int32_t n_
     GatherBatch b; b.n = n_items;
     for (int k = 0; k < n_items; ++k) {
         const mmvae_gather_item& it = items_host[k];
-        if (!it.src || !it.dst || it.row_bytes <= 0 || it.row_bytes % 8 || it.src_row_stride % 8 || it.dst_row_stride % 8 ||
-            ((uintptr_t)it.src & 7) || ((uintptr_t)it.dst & 7)) return MMVAE_ERR_ARG;
+        if (!it.src || !it.dst || it.row_bytes <= 0 || it.row_bytes % 4 || it.src_row_stride % 4 || it.dst_row_stride % 4 ||
+            ((uintptr_t)it.src & 3) || ((uintptr_t)it.dst & 3)) return MMVAE_ERR_ARG;
         b.it[k] = it;
     }
     const long waves = (long)rows * n_items;

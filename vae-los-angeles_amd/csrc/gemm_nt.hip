@@ -297,6 +297,8 @@ static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >
 static int g_nt3_mode = getenv("MMVAE_NT3") ? atoi(getenv("MMVAE_NT3")) : 0;       // 0 = off, 1 = store epilogues, 2 = every epilogue
 static int g_nt2_on = getenv("MMVAE_NO_NT2") ? 0 : 1;
 void tn_wide_enable(int on);             // gemm_tn_wide.hip (mmvae_set_tuning key 4)
+int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st);      // gemm_ntp.hip: the wave-specialised kernel; 1 << 30 = not taken
+void ntp_set(int key, int value);        // mmvae_set_tuning keys 8 (on / off), 9 (minimum M)
 long g_block_bytes = 1L << 31;          // row-block size for operands of >= 4 GiB (mmvae_set_tuning key 3 sets log2; shared with gemm_tn.hip)
 long g_split_bytes = 1L << 32;          // operands of at least this many bytes are processed in row blocks
 
@@ -480,6 +482,7 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     if (key == 5) { mm::g_nt2_f32 = value; return 0; }
     if (key == 6) { mm::g_bnbwd_stream = value; return 0; }
     if (key == 7) { mm::g_relu_stream = value; return 0; }
+    if (key == 8 || key == 9) { mm::ntp_set(key, value); return 0; }
     return MMVAE_ERR_ARG;
 }
 
@@ -507,7 +510,9 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
             s.M = (int32_t)((a->M - r0 < rows) ? a->M - r0 : rows);
             s.a = (const char*)a->a + r0 * a_row;
             if (a->c) s.c = (char*)a->c + r0 * a->ldc * (a->c_dtype == MMVAE_BF16 ? 2 : 4);
-            const long hsz = (a->prec == MMVAE_PREC_BF16) ? 2 : 4;      // H is activation-typed
+            // H is activation-typed, except for the loss epilogues, whose H is the fp32 target
+            const bool loss_epi = a->epilogue == MMVAE_EPI_LOSS_MSE || a->epilogue == MMVAE_EPI_LOSS_BCE_LOGIT;
+            const long hsz = (a->prec == MMVAE_PREC_BF16 && !loss_epi) ? 2 : 4;
             if (a->h) s.h = (const char*)a->h + r0 * a->ldh * hsz;
             if (a->pro_mask) s.pro_mask = a->pro_mask + r0 * a->ld_pro_mask;
             if (a->epi_mask) s.epi_mask = a->epi_mask + r0 * a->ld_epi_mask;
@@ -517,6 +522,7 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
         return 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    { const int rc = mm::ntp_dispatch(a, st); if (rc != (1 << 30)) return rc; }
     if (a->prec == MMVAE_PREC_BF16) return mm::dispatch_src<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::dispatch_src<float>(a, st);
     return MMVAE_ERR_ARG;

@@ -1,0 +1,53 @@
+// Dispatch of the wave-specialised NT GEMM (gemm_ntp.h): which mmvae_gemm_nt problems it takes.
+#include "common.h"
+#include "mmvae_hip.h"
+#include "gemm_ntp.h"
+
+namespace mm {
+
+static int g_ntp_on = getenv("MMVAE_NO_NTP") ? 0 : 1;        // mmvae_set_tuning key 8 (tests flip it to compare with the tile kernels)
+static int g_ntp_min_m = 16384;                               // key 9: below this a persistent 256-workgroup grid has < 1 tile per CU
+void ntp_set(int key, int value) { if (key == 8) g_ntp_on = value; else g_ntp_min_m = value; }
+
+template <typename AT, typename Epi>
+static int ntp_cfg(const mmvae_gemm_nt_args* a, const Epi& e, hipStream_t st) {
+    if (a->N % 256 == 0) return launch_ntp<NtpCfg<4, 4>, AT, Epi>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st);
+    return launch_ntp<NtpCfg<4, 2>, AT, Epi>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st);
+}
+
+template <typename AT>
+static int ntp_epi(const mmvae_gemm_nt_args* a, hipStream_t st) {
+    const bool stats = a->stat1 != nullptr || a->stat2 != nullptr;
+    if (a->c_dtype == MMVAE_BF16) {
+        // whole tiles and whole 128-byte output lines only (the kernel's epilogue has no edge handling; the tile kernels do)
+        const int bn = a->N % 256 == 0 ? 256 : 128;
+        if (a->M % 128 || a->N % bn || a->ldc % 64 || ((uintptr_t)a->c & 127)) return NTP_SKIP;
+        if (stats) { EpiStore<bf16, true> e{(bf16*)a->c, a->ldc, a->bias, a->act, 0, nullptr, 0, nullptr, 0, a->stat1, a->stat2};
+                     return ntp_cfg<AT>(a, e, st); }
+        EpiStore<bf16, false> e{(bf16*)a->c, a->ldc, a->bias, a->act, 0, nullptr, 0, nullptr, 0, nullptr, nullptr};
+        return ntp_cfg<AT>(a, e, st);
+    }
+    return NTP_SKIP;
+}
+
+// NTP_SKIP: not taken (the caller continues with the tile kernels); anything else is the launch status
+int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st) {
+    if (!g_ntp_on || a->prec != MMVAE_PREC_BF16 || a->prologue != MMVAE_PRO_NONE || a->epilogue != MMVAE_EPI_STORE || a->accumulate) return NTP_SKIP;
+    if (a->K <= 64 || a->M < g_ntp_min_m || a->M % 8) return NTP_SKIP;      // M % 8: see the A producers' row groups
+    if (a->a_dtype == MMVAE_F32) {
+        if (a->K < 4 || ((uintptr_t)a->a & 3)) return NTP_SKIP;
+        return ntp_epi<float>(a, st);
+    }
+    return NTP_SKIP;
+}
+
+}  // namespace mm
+
+#ifdef MM_STAMP
+extern "C" int mmvae_debug_ntp_stamps(unsigned long long* out24, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(mm::mm_ntp_stamps), 24 * sizeof(unsigned long long));
+    if (e != hipSuccess) return (int)e;
+    if (reset) { unsigned long long z[24] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(mm::mm_ntp_stamps), z, sizeof(z)); }
+    return (int)e;
+}
+#endif

@@ -324,6 +324,36 @@ def read_losses(out5):
     return vals[:4]
 
 
+class ReparamFn(torch.autograd.Function):
+    """Stand-alone reparameterize(mu, logvar) (reference src/models/vae.py:11-15) on the HIP kernels: the fused
+    mean-fusion + reparameterisation launch with ONE modality; backward d_mu = g, d_logvar = g * eps * exp(logvar / 2) / 2."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        if not (mu.is_cuda and logvar.is_cuda):
+            raise RuntimeError(f"reparameterize: the MI355X path needs CUDA/HIP tensors (got {mu.device}); there is no CPU fallback")
+        if mu.dim() != 2 or mu.shape != logvar.shape:
+            raise RuntimeError(f"reparameterize: expected two (B, L) tensors, got {tuple(mu.shape)} and {tuple(logvar.shape)}")
+        B, Ld = mu.shape
+        heads = torch.cat([mu.detach().float(), logvar.detach().float()], dim=1).contiguous()
+        eps = engine_noise().draw(B, [], Ld, mu.device)[1]
+        mu_o, lv_o = torch.empty_like(heads[:, :Ld]).contiguous(), torch.empty_like(heads[:, :Ld]).contiguous()
+        z = torch.empty(B, Ld, dtype=torch.float32, device=mu.device)
+        with ops.pinned_stream():
+            ops.fuse_reparam_fwd(B, Ld, heads, None, None, None, eps, mu_o, lv_o, z)
+        ctx.save_for_backward(eps, lv_o)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        eps, lv = ctx.saved_tensors
+        B, Ld = lv.shape
+        d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=g.device)
+        with ops.pinned_stream():
+            ops.fuse_reparam_bwd(B, Ld, 1, None, None, [g.contiguous().float()], eps, lv, d_heads, None, None)
+        return d_heads[:, :Ld], d_heads[:, Ld:]
+
+
 # --------------------------------------------------------------------------------------------
 # stand-alone blocks (EncoderA/B/C and DecoderA/B/C used on their own)
 # --------------------------------------------------------------------------------------------

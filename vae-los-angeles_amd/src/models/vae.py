@@ -12,10 +12,10 @@ from .decoders import DecoderA, DecoderB, DecoderC
 
 def reparameterize(mu, logvar):
     """z = mu + eps * exp(0.5*logvar), eps ~ N(0,1) sampled in train AND eval (vae.py:11-15).
-    Stand-alone helper: eps comes from the device Philox stream; inside the models the same
-    arithmetic is fused with the modality mean (mmvae_fuse_reparam_fwd)."""
-    eps = engine.GLOBAL_NOISE.draw(mu.shape[0], [], mu.shape[1], mu.device)[1] if mu.is_cuda else torch.randn_like(mu)
-    return mu + eps * torch.exp(0.5 * logvar)
+    Stand-alone helper: eps comes from the device Philox stream and the arithmetic runs in
+    mmvae_fuse_reparam_fwd / _bwd with one modality (inside the models the same launch also takes
+    the modality mean).  CPU tensors raise: there is no CPU fallback."""
+    return F_.ReparamFn.apply(mu, logvar)
 
 
 class MultiModalVAE(HipModule):

@@ -121,6 +121,12 @@ def run(kind, argv=None):
         args.n_sites = int(site.max()) + 1
     else:
         tpm, beta_v, site = synthetic_dataset(args.samples, args.input_dim_a, args.input_dim_b, args.n_sites, Config.RANDOM_SEED)
+    # class indices are validated ONCE, on the host, before any rank trains: inside the loop a bad label only shows up in the loss
+    # read of the rank that holds it (read_losses raises there) and the other ranks would wait in the all-reduce.  -100 is
+    # F.cross_entropy's ignore_index (losses.py:39): legal for the loss, but the site encoder's Embedding has no row for it.
+    lo_, hi_ = int(site.min()), int(site.max())
+    if lo_ < 0 or hi_ >= args.n_sites:
+        raise SystemExit(f"site labels must lie in [0, {args.n_sites}); found [{lo_}, {hi_}]")
     n = tpm.shape[0]
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(Config.RANDOM_SEED))       # train_test_split(random_state=42) stand-in
     n_val = int(n * Config.TRAIN_TEST_SPLIT)
