@@ -37,13 +37,13 @@ enum { MMVAE_ACT_NONE = 0, MMVAE_ACT_RELU = 1, MMVAE_ACT_SIGMOID = 2 };
 #define MMVAE_TILE 128          /* GEMM output tile edge */
 
 int mmvae_abi_version(void);    /* bumped on any struct change; the ctypes binding checks it */
-/* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernel (default 32768); key 1 = use of the
- * 256x256-tile kernel gemm_nt3.h (0 off, 1 plain store epilogues, 2 every epilogue); key 2 = second-generation kernel gemm_nt2.h on/off;
- * key 3 = log2 of the operand size in bytes from which row blocks are used (17..32; 0 = default 32).  mmvae_gemm_nt / mmvae_gemm_tn address their row operands with
- * 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32 at the scaled omics widths) is processed in row blocks of
- * at most half that threshold (2 GiB) inside the entry point; key 3 lowers it so that tests reach that path at moderate sizes;
- * key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off; key 5 = LDS-DMA form of the NT kernel for fp32 A
- * operands (gemm_nt2.h) on/off (default off: measured equal); key 6 / key 7 = row-coalesced LDS form of the BatchNorm-backward / ReLU-mask dX epilogue on/off. */
+/* Tuning knobs (tests / A-B runs): key 0 = minimum M for the 128x256-tile NT kernels (default 32768); key 2 = LDS-DMA generation of the
+ * NT kernel (gemm_nt2.h) on/off; key 3 = log2 of the operand size in bytes from which row blocks are used (17..32; 0 = default 32):
+ * mmvae_gemm_nt / mmvae_gemm_tn address their row operands with 32-bit offsets, so an operand of 4 GiB or more (65 536 x 27 000 fp32
+ * at the scaled omics widths) is processed in row blocks of at most half that threshold inside the entry point, and key 3 lowers it so
+ * that tests reach that path at moderate sizes; key 4 = wide-tile kernel for the large weight gradients (gemm_tn_wide.hip) on/off;
+ * key 6 / key 7 = row-coalesced LDS form of the BatchNorm-backward / ReLU-mask dX epilogue on/off; key 8 = wave-specialised NT kernel
+ * (gemm_ntp.h: producer / consumer waves) on/off, key 9 = its minimum M (default 16384).  Other keys: MMVAE_ERR_ARG. */
 int mmvae_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -67,9 +67,9 @@ int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* 
  *   W        prepared operand [ceil128(N)][ceil64(K)] in compute type, ldw % 64 == 0
  *   A (bf16) rows are padded to a multiple of 8 elements and the pad columns must hold ZEROS (every producer in this library writes
  *            them): the LDS-DMA kernels move whole 16-byte chunks and multiply the pads with the zero padding of W -- 0 x NaN bits is NaN
- *   h, masks are [M][ld] matrices: a kernel may READ a whole row of ld elements from a row's first element (tiles are loaded in
- *            full 128-byte lines).  For a column slice of a wider buffer that reaches past the slice's row end -- harmless inside the
- *            buffer, so the buffer's tail must extend 512 bytes beyond its last row (mmvae.engine pads the merged decoder stem)
+ *   h, masks are [M][ld] matrices whose rows hold N elements rounded up to the padding of the activation buffers (8 elements; masks:
+ *            4 bytes): a kernel reads nothing beyond that from a row's first element, so h may be a column slice of a wider buffer
+ *            (the merged first layers of the decoders) without any tail padding
  *   prologue MMVAE_PRO_BN_RELU_DROP: A is the previous layer's PRE-BatchNorm output (activation
  *            type); the kernel applies relu(A*pro_scale[k]+pro_shift[k]) * keep/(1-p) on the fly
  *            (encoders.py:14-16,32-34,36-38).  pro_mask: uint8 keep mask [M][ld_pro_mask], bytes 0 or 1 (mmvae_noise), or NULL.

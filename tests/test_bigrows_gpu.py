@@ -78,6 +78,53 @@ def test_row_blocks_do_not_change_a_training_step(prec):
     assert worst <= (1e-4 if prec == "fp32" else 5e-3)
 
 
+def test_row_blocks_do_not_change_the_fused_training_step():
+    """The captured training step computes the reconstruction losses inside the decoders' last GEMMs (EPI_LOSS_MSE /
+    EPI_LOSS_BCE_LOGIT): their epilogue operand is the fp32 TARGET, not an activation.  With the row-block path forced (1 MiB blocks)
+    every block must read its own target rows -- a block advanced by the activation size read the targets of other rows (round-2
+    advisor finding): loss sums and every gradient against the single-launch step."""
+    from mmvae import functional as F_
+    A, D, S, L, B = 782, 572, 24, 20, 4096
+    torch.manual_seed(13)
+    model = MultiModalVAE(A, D, S, L).to(DEV).set_precision("bf16").train()
+    a, b, site = _batch(B, A, D, S, 14)
+    dev = torch.device(DEV, torch.cuda.current_device())
+    lib = _lib.load()
+    res = []
+    for log2 in (0, 21):
+        assert lib.mmvae_set_tuning(3, log2) == 0
+        try:
+            engine.GLOBAL_NOISE.offset_tensor(dev).zero_()
+            for m in model.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.reset_running_stats()
+            gr = model._graph()
+            gr.fused_recon = [a, b, None]
+            try:
+                ra, rb, rc, mu, lv = model(a=a, b=b, site=site)
+            finally:
+                gr.fused_recon = None
+            assert ra.stride(0) == 0 and rb.stride(0) == 0
+            total, out5 = F_.fused_loss({"a": (ra, a), "b": (rb, b), "c": (rc, site), "kl": (mu, lv)}, 1e-3, 1.0)
+            for p in model.parameters():
+                p.grad = None
+            total.backward()
+            torch.cuda.synchronize()
+            res.append((out5.cpu().numpy().copy(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        finally:
+            lib.mmvae_set_tuning(3, 0)
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1[:4], l0[:4], rtol=1e-4)
+    worst = 0.0
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        if g0[k].abs().max().item() < 1e-3 * max(1e-30, gmax):
+            continue
+        worst = max(worst, ((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30)).item())
+    report(f"fused step, row blocks (1 MiB forced) vs single launches, B=4096 bf16: loss rel {np.abs(l1[:4] / l0[:4] - 1).max():.2e}, grad Frobenius-rel max {worst:.2e}")
+    assert worst <= 5e-3
+
+
 def test_entry_points_reject_bad_block_size():
     lib = _lib.load()
     assert lib.mmvae_set_tuning(3, 8) == -1 and lib.mmvae_set_tuning(3, 40) == -1 and lib.mmvae_set_tuning(3, 0) == 0

@@ -223,3 +223,27 @@ def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
     assert sums2[1 - k].item() == 0.0
     with pytest.raises(RuntimeError):                                             # one K step only: not this kernel's case
         ops.gemm_nt(PREC_BF16, A[:, :64].contiguous(), pl.w, N, 64, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[0:1])
+
+
+@pytest.mark.parametrize("S,weighted", [(24, False), (24, True), (40, True)])
+def test_class_term_ignore_index(S, weighted):
+    """F.cross_entropy's default ignore_index = -100 (losses.py:39 passes none): such a row adds no loss and gets a zero gradient in
+    the reference; here it must not count as an out-of-range label either.  Against torch's own cross_entropy on the same logits
+    (both class-term code paths: S <= 32 one row per half wave, S > 32 one row per thread)."""
+    B = 777
+    g = torch.Generator().manual_seed(S)
+    logits = torch.randn(B, S, generator=g)
+    site = torch.randint(0, S, (B,), generator=g)
+    site[::7] = -100
+    cw = (torch.rand(S, generator=g) + 0.5) if weighted else None
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, site, weight=cw, reduction="sum")
+    ref.backward()
+    ld, sd = logits.to(DEV), site.to(DEV)
+    gc = torch.full_like(ld, 7.0)
+    sums = torch.zeros(5, dtype=torch.float64, device=DEV)
+    ops.vae_loss(B, logits=ld, site=sd, class_weights=None if cw is None else cw.to(DEV), gamma=1.0, sums=sums, g_c=gc)
+    assert sums[4].item() == 0.0                                             # -100 is not "outside [0, S)"
+    np.testing.assert_allclose(sums[2].item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(gc.cpu().numpy(), lr.grad.numpy(), atol=2e-6)
+    assert float(gc[::7].abs().max()) == 0.0

@@ -136,6 +136,11 @@ def test_gather_rows_kernel():
     assert torch.equal(oa, A[idx]) and torch.equal(ob, Bm[idx]) and torch.equal(os_, S[idx])
     with pytest.raises(ValueError):
         ops.gather_rows([(A, ob)], idx, N)
+    # odd fp32 widths (INPUT_DIM_* overrides of the reference's config): rows are only 4-byte aligned -> 4-byte words
+    A2 = torch.randn(N, 781, generator=g).to(DEV); B2 = torch.rand(N, 571, generator=g).to(DEV)
+    oa2, ob2 = torch.empty(B, 781, device=DEV), torch.empty(B, 571, device=DEV)
+    ops.gather_rows([(A2, oa2), (B2, ob2), (S, os_)], idx, N)
+    assert torch.equal(oa2, A2[idx]) and torch.equal(ob2, B2[idx]) and torch.equal(os_, S[idx])
 
 
 def test_graphed_step_follows_beta_and_lr_without_recapture():

@@ -24,7 +24,6 @@
 namespace mm { __device__ unsigned long long mm_stamps[12]; }
 #endif
 #include "gemm_nt2.h"
-#include "gemm_nt3.h"
 
 namespace mm {
 
@@ -197,7 +196,7 @@ void gemm_nt_kernel(Src src, const CT* __restrict__ W, long ldw, int M, int N, i
     };
 
     EpiOperands<Epi> eops;
-    auto pre = [&]() { nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc); };     // no-op unless the operands are 16-byte addressable
+    auto pre = [&]() { nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, N, BN, lane, wr, wc); };     // no-op unless the operands are 16-byte addressable
 
     // hipcc's s_waitcnt insertion is only as precise as the control flow lets it be: a fetch under `if (kt + 3 < nk)`
     // means "maybe 8 fewer loads in flight" at the next stage(), and the wait degrades to vmcnt(0) -- every K step then
@@ -289,12 +288,8 @@ static int launch_nt_wn(const Src& src, const void* W, long ldw, int M, int N, i
 }
 
 static int g_wide_min_m = 256 * 128;      // 128x256 tiles only when there are >= 256 row tiles (mmvae_set_tuning key 0)
-// kernel-generation switches (mmvae_set_tuning keys 1, 2; initial values from MMVAE_NT3 / MMVAE_NO_NT2): tests and tools flip
-// them inside one process to compare the generations on the same data
-// gemm_nt3.h is OFF by default: interleaved A/B (tools/bench_nt3.py) put the 256 x 256 tiles within +-4 % of the 128-wide kernels
-// on every hot shape (halving the L2 -> CU operand traffic bought nothing: the K loops are latency-bound, MFMA pipe busy 28 %,
-// DESIGN.md section 5) and 60 % behind on the BatchNorm-backward epilogue (scratch spills at 128 accumulators per lane)
-static int g_nt3_mode = getenv("MMVAE_NT3") ? atoi(getenv("MMVAE_NT3")) : 0;       // 0 = off, 1 = store epilogues, 2 = every epilogue
+// kernel-generation switch (mmvae_set_tuning key 2; initial value from MMVAE_NO_NT2): tests flip it inside one process to compare
+// the register-staged and the LDS-DMA generation on the same data
 static int g_nt2_on = getenv("MMVAE_NO_NT2") ? 0 : 1;
 void tn_wide_enable(int on);             // gemm_tn_wide.hip (mmvae_set_tuning key 4)
 int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st);      // gemm_ntp.hip: the wave-specialised kernel; 1 << 30 = not taken
@@ -309,11 +304,6 @@ static inline bool nt_wide_ok(int M, int N) {
     return !off && N % 256 == 0 && ((long)M * (N / 256) >= (long)g_wide_min_m || M >= g_wide_min_m);
 }
 
-template <typename T> struct IsPlainF32x4 { static constexpr bool value = false; };
-template <> struct IsPlainF32x4<SrcPlain<bf16, float, 4>> { static constexpr bool value = true; };
-// measured equal to the register staging on EncoderB.L0.fwd (96 vs 97-101 us, tools/bench_ntf32.py; the layer is bound by the 64 KB
-// of A + W a CU ingests per K step either way): off by default, kept as the A/B arm (mmvae_set_tuning key 5, MMVAE_NT2_F32=1)
-static int g_nt2_f32 = getenv("MMVAE_NT2_F32") ? 1 : 0;
 static int g_bnbwd_stream = getenv("MMVAE_NO_BNBWD_STREAM") ? 0 : 1;          // mmvae_set_tuning key 6
 static int g_relu_stream = getenv("MMVAE_NO_RELU_STREAM") ? 0 : 1;            // mmvae_set_tuning key 7
 template <typename T> struct IsPlainBf16 { static constexpr bool value = false; };
@@ -322,10 +312,6 @@ template <> struct IsPlainBf16<SrcPlain<bf16, bf16, 8>> { static constexpr bool 
 template <typename CT, typename Src, typename Epi>
 static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
     if constexpr (sizeof(CT) == 2 && IsPlainBf16<Src>::value) {
-        // 256 x 256 tiles (gemm_nt3.h): wide layers with enough rows for a full round of 256-row tiles
-        const int nt3 = g_nt3_mode;
-        if (nt3 && K > 32 && N >= 256 && M >= 256 * 64 && !epi.accumulate_requested() && (Epi::NEED == 0 || nt3 >= 2))
-            return launch_nt3<Epi>(src.p, src.lda, W, ldw, M, N, K, epi, st);
         // second-generation kernel (gemm_nt2.h): operands that go into the MFMA as they are, at least two K steps
         const bool off = !g_nt2_on;
         // ... and for epilogues without operands of their own: with a saved activation / keep mask to fetch, the epilogue's loads
@@ -336,11 +322,6 @@ static int launch_nt(const Src& src, const void* W, long ldw, int M, int N, int 
             if (!narrow && nt_wide_ok(M, N)) return launch_nt2<Epi, 4>(src.p, src.lda, W, ldw, M, N, K, epi, st);
             return launch_nt2<Epi, 2>(src.p, src.lda, W, ldw, M, N, K, epi, st);
         }
-    }
-    if constexpr (sizeof(CT) == 2 && IsPlainF32x4<Src>::value && Epi::NEED == 0) {
-        // fp32 A with 16-byte aligned rows (EncoderB.L0: the caller's input batch): the raw tile by LDS-DMA, converted at fragment time
-        // (gemm_nt2.h, AT = float); 128 x 256 tiles only -- a 128-column tile's ring would leave one 4-wave workgroup per CU
-        if (g_nt2_f32 && K > 64 && !epi.accumulate_requested() && nt_wide_ok(M, N)) return launch_nt2<Epi, 4, float>(src.p, src.lda, W, ldw, M, N, K, epi, st);
     }
     if constexpr (sizeof(CT) == 2) {
         if (nt_wide_ok(M, N) && !epi.accumulate_requested()) return launch_nt_wn<CT, Src, Epi, 4>(src, W, ldw, M, N, K, epi, st);
@@ -470,7 +451,6 @@ static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
 
 extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
     if (key == 0) { mm::g_wide_min_m = value; return 0; }
-    if (key == 1) { mm::g_nt3_mode = value; return 0; }
     if (key == 2) { mm::g_nt2_on = value; return 0; }
     if (key == 3) {         // tests: force the row-block path at moderate sizes (value = log2 of the block bytes; 0 restores the default)
         if (value != 0 && (value < 17 || value > 32)) return MMVAE_ERR_ARG;
@@ -479,7 +459,6 @@ extern "C" int mmvae_set_tuning(int32_t key, int32_t value) {
         return 0;
     }
     if (key == 4) { mm::tn_wide_enable(value); return 0; }
-    if (key == 5) { mm::g_nt2_f32 = value; return 0; }
     if (key == 6) { mm::g_bnbwd_stream = value; return 0; }
     if (key == 7) { mm::g_relu_stream = value; return 0; }
     if (key == 8 || key == 9) { mm::ntp_set(key, value); return 0; }

@@ -24,11 +24,8 @@
 
 namespace mm {
 
-// AT = float (fp32 A: the first encoder layers read the caller's input batch): the RAW fp32 tile goes through the DMA -- a K step of 64
-// elements is two [128][128 B] images (k 0..31, 32..63) with the same swizzle -- and is converted on the way from LDS to the MFMA
-// (two ds_read_b128 + four v_cvt_pk_bf16_f32 per fragment).  The first generation moves that operand global -> VGPR -> convert -> LDS.
-template <int WN, int ASZ = 2> struct Nt2Lds {
-    static constexpr int A_BYTES = TILE * ROW_BYTES * (ASZ / 2);   // 16 KiB (bf16) / 32 KiB (fp32)
+template <int WN> struct Nt2Lds {
+    static constexpr int A_BYTES = TILE * ROW_BYTES;               // 16 KiB
     static constexpr int W_BYTES = 64 * WN * ROW_BYTES;            // 8 KiB * WN
     static constexpr int SLOT = A_BYTES + W_BYTES;
     static constexpr int RING = 2 * SLOT;
@@ -123,7 +120,7 @@ __device__ __forceinline__ void nt2_relumask_epilogue(unsigned char* smem, f32x4
     const int colg = col0 + 4 * c;
     const bf16* __restrict__ H = epi.H;
     bf16* __restrict__ C = epi.C;
-    const int ch_ = min(colg, (int)epi.ldh - 4);
+    const int ch_ = min(colg, ((N + 7) & ~7) - 4);                   // the saved activation has ceil8(N) columns (H may be a column slice: not ldh)
     bf16x4 hv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) hv[i] = *(const bf16x4*)(H + (long)min(row0 + r0 + 8 * i, M - 1) * epi.ldh + ch_);
@@ -168,13 +165,13 @@ __device__ __forceinline__ void nt2_bnbwd_epilogue(unsigned char* smem, const fl
     const uint8_t* __restrict__ K_ = epi.mask;
     bf16* __restrict__ C = epi.C;
     const bool has_mask = K_ != nullptr;
-    const int cy = min(colg, (int)epi.ldy - 4);                      // y rows are padded to 8 columns: a 4-column load inside ldy is in bounds
+    const int cy = min(colg, ((N + 7) & ~7) - 4);                    // y rows are padded to 8 columns: a 4-column load below ceil8(N) is in bounds
     bf16x4 yv[16]; uint32_t mv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const long grow = min(row0 + r0 + 8 * i, M - 1);
         yv[i] = *(const bf16x4*)(Y + grow * epi.ldy + cy);
-        mv[i] = has_mask ? *(const uint32_t*)(K_ + grow * epi.ldm + min(colg, (int)epi.ldm - 4)) : 0x01010101u;
+        mv[i] = has_mask ? *(const uint32_t*)(K_ + grow * epi.ldm + min(colg, ((N + 3) & ~3) - 4)) : 0x01010101u;
     }
     __syncthreads();                                               // every wave has finished reading the ring
 #pragma unroll
@@ -222,15 +219,14 @@ __device__ __forceinline__ void nt2_bnbwd_epilogue(unsigned char* smem, const fl
     __syncthreads();                                               // the ring may be refilled
 }
 
-template <typename Epi, int WN, typename AT = bf16>
+template <typename Epi, int WN>
 __global__ __launch_bounds__(128 * WN, 2)
-void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
+void gemm_nt2_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
 {
     typedef bf16 CT;
-    constexpr bool AF = sizeof(AT) == 4;
-    typedef Nt2Lds<WN, (int)sizeof(AT)> LD;
+    typedef Nt2Lds<WN> LD;
     constexpr int BK = 64, BN = 64 * WN, NW = 2 * WN;
-    constexpr int A_PIECES = (TILE / 8) * (AF ? 2 : 1), W_PIECES = BN / 8;      // 1 KiB pieces (8 rows x 128 B) per slot
+    constexpr int A_PIECES = TILE / 8, W_PIECES = BN / 8;                        // 1 KiB pieces (8 rows x 128 B) per slot
     constexpr int A_PER = A_PIECES / NW, W_PER = W_PIECES / NW;
     typedef Mma<CT>::frag frag;
     typedef EpiCols<sizeof(typename Epi::out_t) == 2> EC;
@@ -241,7 +237,7 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WN, wc = wid % WN;
     const int nk = (K + BK - 1) / BK;
-    const int kmax = AF ? K - 4 : ((K + 7) & ~7) - 8;              // last 16-byte chunk that lies inside an A row (bf16 rows are padded to 8; fp32: K % 4 == 0)
+    const int kmax = ((K + 7) & ~7) - 8;                           // last 16-byte chunk that lies inside an A row (rows are padded to 8 elements)
     const int ntiles = ((gx + 7) / 8) * 8 * gy;                    // tile ids incl. the padding of gx to a multiple of 8
 
     // tile id T -> (row tile, column tile): ids that differ by 8 run on one XCD; the column tiles of a row tile are adjacent there
@@ -261,14 +257,14 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         const int row0 = rt * TILE, col0 = ct * BN;
         unsigned char* sA = smem + slot * LD::SLOT;
         unsigned char* sW = sA + LD::A_BYTES;
-        const AT* Ak = A + kt * BK;                                 // wave-uniform part of the address
+        const bf16* Ak = A + kt * BK;                               // wave-uniform part of the address
         const bf16* Wk = W + kt * BK;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int p = wid + NW * i;
-            const int r = (AF ? (p & 15) : p) * 8 + prow;           // fp32: pieces 0..15 = k 0..31 of the step, 16..31 = k 32..63
+            const int r = p * 8 + prow;
             const int c = ppos ^ (r & 7);
-            const int kc = AF ? min((p >> 4) * 32 + c * 4, kmax - kt * BK) : min(c * 8, kmax - kt * BK);     // chunks past the row end re-read its last chunk (x zero weights)
+            const int kc = min(c * 8, kmax - kt * BK);               // chunks past the row end re-read its last chunk (x zero weights)
             const unsigned off = (unsigned)min(row0 + r, M - 1) * (unsigned)lda + (unsigned)kc;
             __builtin_amdgcn_global_load_lds((gbl_void*)(Ak + off), (lds_void*)(sA + p * 1024), 16, 0, 0);
         }
@@ -291,13 +287,7 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int r = wr * 64 + m * 16 + (lane & 15);
-            if constexpr (AF) {                                     // image s of the step, chunks 2g and 2g+1 of the row: 8 floats
-                const unsigned char* base = sA + s * (TILE * ROW_BYTES) + r * ROW_BYTES;
-                const int c0 = 2 * (lane >> 4);
-                const f32x4 lo = *(const f32x4*)(base + ((c0 ^ (r & 7)) << 4)), hi = *(const f32x4*)(base + (((c0 + 1) ^ (r & 7)) << 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { af[m][e] = (bf16)lo[e]; af[m][4 + e] = (bf16)hi[e]; }
-            } else af[m] = *(const frag*)(sA + r * ROW_BYTES + ((ch ^ (r & 7)) << 4));
+            af[m] = *(const frag*)(sA + r * ROW_BYTES + ((ch ^ (r & 7)) << 4));
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) { const int r = wc * 64 + n * 16 + (lane & 15); bf[n] = *(const frag*)(sW + r * ROW_BYTES + ((ch ^ (r & 7)) << 4)); }
@@ -365,7 +355,7 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
             else nt2_loss_epilogue<Epi, WN>(smem, ecol, red, acc, epi, row0, col0, M, N, tid, lane, wr, wc);
             if (Tn >= 0) issue(Tn, 0, g & 1);                       // the ring is free again (the epilogue ends in a barrier)
         } else {
-            nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, BN, lane, wr, wc);
+            nt_epilogue_prefetch<Epi, 0>(eops, epi, row0, col0, M, N, BN, lane, wr, wc);
             nt_epilogue<CT, Epi, WN>(red, ecol, acc, epi, eops, row0, col0, M, N, tid, lane, wr, wc);
         }
 #ifdef MM_STAMP
@@ -388,23 +378,23 @@ void gemm_nt2_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
 
 // Persistent grid: every CU gets its residency's worth of workgroups (2 of 4 waves, or 1 of 8), a multiple of 8 so that a
 // workgroup keeps to one XCD's tile list.
-template <typename Epi, int WN, typename AT = bf16>
+template <typename Epi, int WN>
 static int launch_nt2(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
-    typedef Nt2Lds<WN, (int)sizeof(AT)> LD;
+    typedef Nt2Lds<WN> LD;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt2_kernel<Epi, WN, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LD::TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt2_kernel<Epi, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LD::TOTAL);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const int gx = (M + TILE - 1) / TILE, gy = (N + 64 * WN - 1) / (64 * WN);
     const int ntiles = ((gx + 7) / 8) * 8 * gy;
     static const int wg_env = getenv("MMVAE_NT2_WGS") ? atoi(getenv("MMVAE_NT2_WGS")) : 0;      // A/B knob: workgroups per CU
-    const int per_cu = wg_env > 0 ? wg_env : ((WN == 2 && sizeof(AT) == 2) ? 2 : 1);
+    const int per_cu = wg_env > 0 ? wg_env : (WN == 2 ? 2 : 1);
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN, AT>), dim3(grid), dim3(128 * WN), LD::TOTAL, st,
-                       (const AT*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
+    hipLaunchKernelGGL((gemm_nt2_kernel<Epi, WN>), dim3(grid), dim3(128 * WN), LD::TOTAL, st,
+                       (const bf16*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
     MM_CHECK_LAUNCH();
     return 0;
 }

@@ -214,8 +214,11 @@ template <typename Epi> __device__ __forceinline__ bool epi_h_vec(const Epi& epi
 // use (8 lanes x 16 bytes per row and instruction) and swapped back into accumulator layout when it is used; loading the
 // two 64-byte halves of a line from separate instructions cost +40 % HBM read traffic (FETCH_SIZE), the line having left
 // the L2 before its second half was asked for.
-template <typename Epi> __device__ __forceinline__ bool epi_h_lines(const Epi& epi, int col0, int BN) {
-    return epi_h_vec(epi) && (epi.ldh * sizeof(typename Epi::h_t)) % 128 == 0 && ((uintptr_t)epi.H & 127) == 0 && col0 + BN <= epi.ldh;
+// ncols: columns of H (and of the mask) a kernel may touch from the row's first element -- the N of the product rounded up to the
+// 8-element padding every activation buffer has, NOT the leading dimension: H may be a column slice of a wider buffer, and for its
+// last slice "inside the leading dimension" reaches past the row end (for the last row: past the allocation).
+template <typename Epi> __device__ __forceinline__ bool epi_h_lines(const Epi& epi, int col0, int BN, int ncols) {
+    return epi_h_vec(epi) && (epi.ldh * sizeof(typename Epi::h_t)) % 128 == 0 && ((uintptr_t)epi.H & 127) == 0 && col0 + BN <= ncols;
 }
 template <typename Epi> __device__ __forceinline__ bool epi_m_vec(const Epi& epi) {
     return Epi::NEED >= 2 && epi.mask != nullptr && epi.ldm % 8 == 0 && ((uintptr_t)epi.mask & 7) == 0;
@@ -227,12 +230,13 @@ template <typename Epi> __device__ __forceinline__ bool epi_m_vec(const Epi& epi
 // the work on the first half) -- all 48 operand registers at once did not fit next to the accumulators and both
 // fragment sets, and hipcc spilled the values it had just loaded.
 template <typename Epi, int HALF>
-__device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, const Epi& epi, int row0, int col0, int M, int BN, int lane, int wr, int wc) {
+__device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, const Epi& epi, int row0, int col0, int M, int N, int BN, int lane, int wr, int wc) {
     typedef EpiOperands<Epi> EO;
     typedef typename EO::EC EC;
     const int li = lane & 15, lg = lane >> 4;
+    const int ncols = (N + 7) & ~7;
     if constexpr (Epi::NEED >= 1) {
-        if (epi_h_lines(epi, col0, BN)) {
+        if (epi_h_lines(epi, col0, BN, ncols)) {
             // slot 2p holds (row 16m + (li & 7), half li >> 3), slot 2p+1 the same half of row 16m + 8 + (li & 7)
 #pragma unroll
             for (int m = 2 * HALF; m < 2 * HALF + 2; ++m)
@@ -250,7 +254,7 @@ __device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, cons
 #pragma unroll
                 for (int g = 0; g < EC::NG; ++g) {
                     const int c = col0 + wc * 64 + EC::base(g, lg);
-                    const uint4 t = *(const uint4*)(epi.H + ro + (c + EC::G <= epi.ldh ? c : 0));
+                    const uint4 t = *(const uint4*)(epi.H + ro + (c + EC::G <= ncols ? c : 0));
                     ops.h[m * EC::NG + g][0] = t.x; ops.h[m * EC::NG + g][1] = t.y; ops.h[m * EC::NG + g][2] = t.z; ops.h[m * EC::NG + g][3] = t.w;
                 }
             }
@@ -264,7 +268,7 @@ __device__ __forceinline__ void nt_epilogue_prefetch(EpiOperands<Epi>& ops, cons
 #pragma unroll
                 for (int g = 0; g < EC::NG; ++g) {
                     const int c = col0 + wc * 64 + EC::base(g, lg);
-                    const uint8_t* q = epi.mask + ro + (c + EC::G <= epi.ldm ? c : 0);
+                    const uint8_t* q = epi.mask + ro + (c + EC::G <= ncols ? c : 0);
                     if constexpr (EO::MD == 2) { const uint2 t = *(const uint2*)q; ops.mk[m * EC::NG + g][0] = t.x; ops.mk[m * EC::NG + g][1] = t.y; }
                     else ops.mk[m * EC::NG + g][0] = *(const uint32_t*)q;
                 }
@@ -309,7 +313,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
     const bool full_lines = !ACCUM && epi.stores() && row0 + tile_rows <= M && col0 + BN <= n_store &&
                             (epi.ldc * sizeof(OT)) % 128 == 0 && ((uintptr_t)epi.C & 127) == 0;
     const unsigned low = (li & 8) ? 0u : 0xffffffffu;           // all-ones on lanes li < 8
-    const bool h_lines = VEC && Epi::NEED >= 1 && epi_h_lines(epi, col0, BN);
+    const bool h_lines = VEC && Epi::NEED >= 1 && epi_h_lines(epi, col0, BN, (N + 7) & ~7);
 #pragma unroll
     for (int p = 0; p < NG / 2; ++p) {
         float s1[2][G], s2[2][G];                               // column partial sums of the two groups, over the lane's 4 rows
@@ -468,7 +472,7 @@ __device__ __forceinline__ void nt_epilogue(float* red, const float* ecol, f32x4
     } else if (!vec) {
         nt_epilogue_body<Epi, -1, false, false>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
     } else {
-        nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, BN, lane, wr, wc);
+        nt_epilogue_prefetch<Epi, 1>(ops, epi, row0, col0, M, N, BN, lane, wr, wc);
         const int a = epi.act_code();
         if (a == 0) nt_epilogue_body<Epi, 0, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);
         else if (a == 1) nt_epilogue_body<Epi, 1, false, true>(ecol, acc, epi, ops, red, want_stats, BN, row0, col0, M, N, lane, wr, wc);

@@ -20,7 +20,6 @@ from .ops import (PREC_BF16, PREC_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, EPI_RELU
 
 _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
-_BN_BWD_RECOMPUTE = os.environ.get("MMVAE_BN_BWD_RECOMPUTE", "0") == "1"
 _FUSE_BN_APPLY = os.environ.get("MMVAE_FUSE_BN_APPLY", "1") == "1"       # A/B switch: BN-backward correction of first layers inside the dW GEMM
 _GROUP_TINY_DW = os.environ.get("MMVAE_GROUP_TINY_DW", "1") == "1"       # A/B switch: small-output dW GEMMs as grouped launches
 _TINY_DW_MAX = 16384                                                       # N*K at or below which a dW GEMM counts as small-output
@@ -134,23 +133,7 @@ def zeros_pack(device, specs):
 _ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.uint8: 1, torch.int64: 8}
 
 
-_SIDE_STREAMS = {}
 _MERGE_DECODER_STEM = os.environ.get("MMVAE_NO_DECODER_STEM") is None          # A/B switch
-
-
-def _side_stream(device, which=0):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
-
-def _fork(src, dst):
-    """dst waits for everything enqueued on src so far (event record + wait)."""
-    ev = torch.cuda.Event()
-    ev.record(src)
-    dst.wait_event(ev)
 
 
 class BNState:
@@ -192,11 +175,9 @@ class EncoderMLP:
     def widths(self):
         return [l.out_features for l in self.linears]
 
-    def forward(self, prec, x, train, masks, stats_bufs=None, masks_ready=None):
+    def forward(self, prec, x, train, masks, stats_bufs=None):
         """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval).
-        stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer.
-        masks_ready: optional (stream, event): the masks are being written on another stream; the first launch that reads
-        one (the SECOND GEMM: a mask is applied on the consumer's operand load) waits for the event."""
+        stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer."""
         B, dev = x.shape[0], x.device
         adt = act_dtype(prec)
         saved = []
@@ -204,9 +185,6 @@ class EncoderMLP:
         nt = (B + TILE - 1) // TILE
         for lin, bn, pl in zip(self.linears, self.bns, self.pl):
             N, K = pl.N, pl.K
-            if masks_ready is not None and pro is not None:
-                masks_ready[0].wait_event(masks_ready[1])
-                masks_ready = None
             y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
             st = BNState(N, dev)
             if train:
@@ -224,8 +202,6 @@ class EncoderMLP:
             saved.append((h, pro, y, st, new_pro))
             h, pro = y, new_pro
         heads = torch.empty(B, 2 * self.latent, dtype=torch.float32, device=dev)
-        if masks_ready is not None and pro is not None:
-            masks_ready[0].wait_event(masks_ready[1])
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
         return heads, saved
 
@@ -250,26 +226,20 @@ class EncoderMLP:
             N, K = pl.N, pl.K
             bnargs = (st.scale, st.shift, st.mean, st.rstd, pro[2], pro[3])
             # BatchNorm/ReLU/Dropout backward of layer i: ONE contraction that stores d = dX * keep * relu' and accumulates
-            # (sum d, sum d*xhat); then the BN correction in place (mmvae_bn_bwd_apply).  The recompute form (two contractions,
-            # nothing stored in between) stays available: MMVAE_BN_BWD_RECOMPUTE=1.
+            # (sum d, sum d*xhat); then the BN correction in place (mmvae_bn_bwd_apply) or on the dW GEMM's operand load.
             stats = stats_bufs[i] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
             coef = torch.empty(3, N, dtype=torch.float32, device=dev)
             d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
-            if _BN_BWD_RECOMPUTE:
-                ops.gemm_nt(prec, src, src_wt, src_n, src_k, None, epilogue=EPI_BN_BWD, h=y, bn=bnargs, stats=stats, tag=f"{self.name}.L{i}.bn_bwd_stats")
-                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
-                ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_coef=coef, tag=f"{self.name}.L{i}.bn_bwd_apply")
-            else:
-                ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
-                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
-                # (not for very wide inputs -- the scaled omics widths: the dW GEMM then has hundreds of K tiles and every one of them
-                # would redo the correction of its P rows; one pass over d is cheaper)
-                if i == 0 and _FUSE_BN_APPLY and K <= 4096:
-                    # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
-                    tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
-                       p_prologue=(y, st.mean, st.rstd, coef), tag=f"{self.name}.L{i}.dW")
-                    continue
-                ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
+            ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
+            ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
+            # (not for very wide inputs -- the scaled omics widths: the dW GEMM then has hundreds of K tiles and every one of them
+            # would redo the correction of its P rows; one pass over d is cheaper)
+            if i == 0 and _FUSE_BN_APPLY and K <= 4096:
+                # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
+                tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
+                   p_prologue=(y, st.mean, st.rstd, coef), tag=f"{self.name}.L{i}.dW")
+                continue
+            ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
             tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
             src, src_wt, src_n, src_k = d, pl.wt, K, N
 
@@ -403,14 +373,9 @@ class VAEGraph:
         self.dec_stem = None
         self.noise = GLOBAL_NOISE
         self.grad_sync = None          # mmvae.parallel.GradAllReduce (early/final hooks) under data parallelism
-        # Independent chains on side HIP streams (EncoderA beside EncoderB, the small decoders beside DecoderB, the dW GEMMs beside
-        # the dX chain, the noise launch beside the first GEMMs).  OFF by default since the kernels got faster: overlapped
-        # HBM-bound kernels only take turns, and the fork/join edges cost more than they buy (2.19 -> 2.15 ms/step at B = 65 536).
-        self.overlap_dw = os.environ.get("MMVAE_OVERLAP_DW", "0") != "0"
-        self.overlap_enc = os.environ.get("MMVAE_OVERLAP_ENC", "1") != "0" and self.overlap_dw
-        self.overlap_dec = os.environ.get("MMVAE_OVERLAP_DEC", "1") != "0" and self.overlap_dw
-        self.overlap_bwd = os.environ.get("MMVAE_OVERLAP_BWD", "1") != "0" and self.overlap_dw
-        self.overlap_noise = os.environ.get("MMVAE_OVERLAP_NOISE", "0") != "0"
+        # (Independent chains on side HIP streams -- EncoderA beside EncoderB, the small decoders beside DecoderB, the dW GEMMs beside
+        # the dX chain, the noise launch beside the first GEMMs -- were measured slower every time the kernels got faster: overlapped
+        # bandwidth-bound kernels only take turns and the fork / join edges cost more than they buy.  One stream.)
         # Training-step fusion (mmvae.graphs): [target or None per decoder].  The next forward then computes those decoders'
         # reconstruction losses inside their last GEMM instead of returning the reconstruction (see DecoderMLP.forward).
         self.fused_recon = None
@@ -461,26 +426,7 @@ class VAEGraph:
         Ld = self.latent
         widths_a = self.enc_a.widths() if (train and xa is not None) else []
         widths_b = self.enc_b.widths() if (train and xb is not None) else []
-        # independent chains run on HIP streams of their own (parallel branches under hipGraph capture): the noise launch
-        # beside the first-layer GEMMs (nothing reads a mask before the second GEMM, eps before the fusion), EncoderA beside
-        # EncoderB, the small decoders beside the largest one.  Every buffer they touch stays referenced until backward.
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if (self.overlap_enc and xa is not None and xb is not None) else None
-        # the noise launch alone beside prep_weights' successors: MMVAE_OVERLAP_NOISE=1 (A/B switch)
-        nside = _side_stream(dev, 1) if ((side is not None or self.overlap_noise) and self.noise._injected is None and train) else None
-        noise_ev = None
-        if nside is not None:
-            _fork(main, nside)
-            with torch.cuda.stream(nside), ops.pinned_stream(nside):
-                masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)
-                for t in masks + [eps]:
-                    t.record_stream(main)
-                    if side is not None:
-                        t.record_stream(side)
-                noise_ev = torch.cuda.Event()
-                noise_ev.record(nside)
-        else:
-            masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
+        masks, eps = self.noise.draw(B, widths_a + widths_b, Ld, dev)       # eps is sampled in eval mode too (vae.py:73)
         # ONE memset for everything this step needs zeroed: forward BatchNorm sums, the loss accumulators, and -- when a backward will
         # follow -- the flat gradient arena with the backward's BatchNorm sums and embedding-table gradient (three fills before)
         st_all = []
@@ -497,27 +443,18 @@ class VAEGraph:
                 saved["grad_pack"] = packed[nst + 2:]
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
-            if side is not None:
-                _fork(main, side)
-            with ops.pinned_stream(side if side is not None else main):
-                heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
-                                                             st_all[:len(widths_a)] if train else None,
-                                                             masks_ready=(side if side is not None else main, noise_ev) if noise_ev is not None else None)
+            heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
+                                                         st_all[:len(widths_a)] if train else None)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
             heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
-                                                         st_all[len(widths_a):] if train else None,
-                                                         masks_ready=(main, noise_ev) if noise_ev is not None else None)
+                                                         st_all[len(widths_a):] if train else None)
         if site is not None:
             if site.dtype != torch.int64:
                 site = site.long()
             site = site.contiguous()
             table = self.enc_c.table()
             saved["site"] = site
-        if noise_ev is not None:
-            main.wait_event(noise_ev)                  # join (eps; also closes the branch when no encoder waited)
-        if side is not None:
-            _fork(side, main)                          # join: the fusion kernel needs EncoderA's heads
         mu = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         logvar = torch.empty(B, Ld, dtype=torch.float32, device=dev)
         z = torch.empty(B, ceil_to(Ld, 8), dtype=act_dtype(prec), device=dev)
@@ -528,16 +465,10 @@ class VAEGraph:
         saved.update(eps=eps, logvar=logvar.detach(), n_mod=(heads_a is not None) + (heads_b is not None) + (table is not None))
         outs, saved["dec"] = [None] * len(self.decoders), [None] * len(self.decoders)
         order = sorted(range(len(self.decoders)), key=lambda i: -sum(l.weight.numel() for l in self.decoders[i].linears))
-        dside = _side_stream(dev) if (self.overlap_dec and len(order) > 1) else None
-        if dside is not None:
-            _fork(main, dside)
         stem = self.dec_stem
         firsts = [None] * len(self.decoders)
         if stem is not None:
-            # Tail padding: a consumer's epilogue loads the saved activation of a whole 128- / 256-column tile in full-line layout when
-            # the tile fits the LEADING DIMENSION -- for the last column slice that runs past the row end, i.e. for the last row past
-            # the buffer (a fault when the allocation ends on a page boundary, as 65 536 x 448 bf16 does).  What is read there is never used.
-            H0 = torch.empty(B * stem.N + 1024, dtype=act_dtype(prec), device=dev)[:B * stem.N].view(B, stem.N)
+            H0 = torch.empty(B, stem.N, dtype=act_dtype(prec), device=dev)
             ops.gemm_nt(prec, z, stem.w, stem.N, stem.K, H0, bias=stem.bias, act=ACT_RELU, tag="Decoders.L0.fwd")
             off = 0
             for i, d in enumerate(self.decoders):
@@ -548,21 +479,18 @@ class VAEGraph:
         if want is not None and any(t is not None and self.decoders[i].can_fuse_loss(prec) for i, t in enumerate(want)):
             sums, out5 = saved["loss_ws"] if "loss_ws" in saved else ops.loss_workspace(dev)
             fused = saved["fused_recon"] = {"sums": sums, "out5": out5, "g": {}, "targets": {}}
-        for rank_, i in enumerate(order):               # largest decoder on the main stream, the others beside it
+        for i in order:                                 # largest decoder first
             dec = self.decoders[i]
             tgt = want[i] if (fused is not None and want[i] is not None and dec.can_fuse_loss(prec)) else None
-            with ops.pinned_stream(dside if (dside is not None and rank_ > 0) else main):
-                if tgt is not None:
-                    k = 1 if dec.final_sigmoid else 0                     # sums[0] = MSE, sums[1] = BCE (mmvae_vae_loss)
-                    g, acts = dec.forward(prec, z, fused_loss=(tgt, fused["sums"][k:k + 1]), first=firsts[i])
-                    fused["g"][i], fused["targets"][i] = g, tgt
-                    o = torch.empty(1, dtype=torch.float32, device=dev).expand(B, dec.out_dim)     # placeholder: no storage behind it
-                else:
-                    o, acts = dec.forward(prec, z, first=firsts[i])
+            if tgt is not None:
+                k = 1 if dec.final_sigmoid else 0                     # sums[0] = MSE, sums[1] = BCE (mmvae_vae_loss)
+                g, acts = dec.forward(prec, z, fused_loss=(tgt, fused["sums"][k:k + 1]), first=firsts[i])
+                fused["g"][i], fused["targets"][i] = g, tgt
+                o = torch.empty(1, dtype=torch.float32, device=dev).expand(B, dec.out_dim)     # placeholder: no storage behind it
+            else:
+                o, acts = dec.forward(prec, z, first=firsts[i])
             outs[i] = o
             saved["dec"][i] = (acts, o.detach())
-        if dside is not None:
-            _fork(dside, main)
         return outs, mu, logvar, saved
 
     def _grad_specs(self, has_a, has_b, has_site):
@@ -605,13 +533,10 @@ class VAEGraph:
                                               packed=saved.pop("grad_pack", None))
         st_bwd = [t.view(2, -1) for t in extra[:-1]]
         dzs = []                                       # one dL/dz per decoder; summed in mmvae_fuse_reparam_bwd
-        # dW/db GEMMs have no consumer before the optimiser: they run on a second HIP stream beside the dX chain
-        # (under hipGraph capture this becomes a parallel branch of the graph)
         # slab workspace for the split-batch dW GEMMs (<= 64 splits of the largest weight matrix); launches that use it
         # run one after another on one stream, so a single buffer serves them all
         big = max(p.numel() for p in self.param_list())
         slab = torch.empty(min(64 * big, 1 << 25), dtype=torch.float32, device=dev)     # <= 128 MiB; too small -> that GEMM uses atomics
-        keep = []
 
         # Small-output dW GEMMs (latent / class widths: encoder heads, decoder first layers, DecoderC) are latency chains when
         # launched alone (~25 us each for a few MB + a reduce launch): they are DEFERRED and run as one grouped launch + one
@@ -629,18 +554,6 @@ class VAEGraph:
                 need = ops.TN_GROUP_SPLITS * sum(t_["N"] * t_["K"] for t_ in tiny)
                 ops.gemm_tn_group(prec, tiny, torch.empty(need, dtype=torch.float32, device=dev), tag=tag)
                 tiny.clear()
-        main = torch.cuda.current_stream()
-        # all dW GEMMs of one backward share the slab workspace: they must stay on ONE stream (main, or the side stream)
-        side = _side_stream(dev) if self.overlap_bwd else None
-        if side is not None:
-            def tn(prec_, p, q, *a, **kw):                # (A/B form: no deferral, every dW GEMM beside the dX chain)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                keep.extend((p, q))                       # operands stay alive until the join below
-                keep.extend(kw.get("p_prologue") or ())
-                with ops.pinned_stream(side):
-                    ops.gemm_tn(prec_, p, q, *a, slab=slab, **kw)
         stem = self.dec_stem if all(g is not None for g in g_outs) else None      # every decoder must fill its slice
         D0, off = None, 0
         if stem is not None:
@@ -665,10 +578,6 @@ class VAEGraph:
         if self.grad_sync is not None:                    # data parallel: the decoder gradients must be final for the early all-reduce bucket;
             flush_tiny("tiny_dW.decoders")                # otherwise they wait for the encoder heads and share ONE grouped launch + reduce
         if self.grad_sync is not None:
-            if side is not None:                          # the decoder dW launches live on the side stream
-                ev = torch.cuda.Event()
-                ev.record(side)
-                main.wait_event(ev)
             # decoder gradients (tail of the arena) are final: start reducing them under the encoder backward
             self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
         n_mod = saved["n_mod"]
@@ -684,11 +593,6 @@ class VAEGraph:
         if site is not None:
             self.enc_c.backward(d_table, grads)
         flush_tiny("tiny_dW.heads")
-        if side is not None:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            main.wait_event(ev)
-            keep.clear()
         if self.grad_sync is not None:
             self.grad_sync.final(flat)
         return flat, grads
