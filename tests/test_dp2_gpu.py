@@ -1,0 +1,176 @@
+"""Two processes through the HIP engine (VERDICT round 2, next #2b).
+
+Two ranks share cuda:0 (the GPU box has one card; RCCL refuses two ranks on one device, so the collective is gloo -- the
+data path, the arena layout, the early/final hooks, the three-graph launch form and AdamW are exactly what the 8-GPU run
+uses).  Each rank trains on its contiguous row shard; this process then restates the SAME two shards one after the other with
+the same per-rank Philox streams, sums the two gradient arenas itself (all loss terms are reduction='sum',
+/root/reference/src/utils/losses.py:31,34,39,42 -> SUM, not mean) and applies AdamW: reduced arenas and parameters must agree.
+Also: bench.py --gpus 2 starting its own ranks, and trainer.py under two ranks (equal steps, identical decisions)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+DEV = "cuda"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(argv, world=2, timeout=600, cwd=None, extra_env=None):
+    """Start `world` processes with the torchrun environment; returns their (returncode, stdout, stderr)."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH="")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd))
+    res = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        res.append((p.returncode, o, e))
+    return res
+
+
+def _restate_two_ranks(prec, steps):
+    """Both shards in THIS process: two replicas (per-shard BatchNorm buffers), gradients summed by hand, AdamW on the sum."""
+    import dp2_worker as W
+    from mmvae import engine, parallel
+    from mmvae.optim import FusedAdamW
+    from src.models import MultiModalVAE
+    from src.utils import vae_loss
+    dev = torch.device(DEV, torch.cuda.current_device())
+    a, b, site = W.make_global_batch()
+    reps = []
+    for r in range(2):
+        torch.manual_seed(W.SEED)                            # rank 0's weights (what broadcast_parameters hands to everybody)
+        m = MultiModalVAE(W.A, W.D, W.S, W.L).to(dev).set_precision(prec).train()
+        lo, hi = parallel.shard_rows(W.B_GLOBAL, r, 2)
+        reps.append(dict(model=m, opt=FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5), offset=0,
+                         a=a[lo:hi].to(dev), b=b[lo:hi].to(dev), s=site[lo:hi].to(dev)))
+    torch.manual_seed(W.SEED)
+    noise = engine.GLOBAL_NOISE
+    losses = []
+    try:
+        for _ in range(steps):
+            flats, step_loss = [], []
+            for r, R in enumerate(reps):
+                noise.stream_rank = r                        # rank r's Philox key ...
+                noise.load_state_dict({"offset": R["offset"]}, dev)     # ... at rank r's position
+                ra, rb, rc, mu, lv = R["model"](a=R["a"], b=R["b"], site=R["s"])
+                loss, *_ = vae_loss(ra, R["a"], rb, R["b"], rc, R["s"], mu, lv, beta=1e-3, gamma=1.0)
+                R["opt"].zero_grad()
+                loss.backward()
+                R["offset"] = noise.state_dict(dev)["offset"]
+                flats.append(W.flat_grads(R["model"]))
+                step_loss.append(float(loss.item()))
+            total = flats[0] + flats[1]
+            for R in reps:
+                o = 0
+                for p in R["model"]._graph().param_list():
+                    p.grad.copy_(total[o:o + p.numel()].view_as(p.grad))
+                    o += p.numel()
+                R["opt"].step()
+            losses.append(step_loss)
+    finally:
+        noise.stream_rank = None
+        noise.load_state_dict({"offset": 0}, dev)
+    return total.cpu(), reps, losses
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_two_ranks_through_the_hip_engine(tmp_path, prec):
+    import dp2_worker as W
+    from model_util import CHAOTIC_BIASES
+    want_g, reps, want_losses = _restate_two_ranks(prec, W.STEPS)
+    worker = os.path.join(HERE, "dp2_worker.py")
+    for mode in ("eager", "graph_overlap", "graph_single"):
+        res = _run_ranks([worker, mode, prec, str(tmp_path)])
+        for rc, o, e in res:
+            assert rc == 0, (mode, e[-3000:])
+        got = [torch.load(tmp_path / f"{mode}_{prec}_rank{r}.pt", weights_only=True) for r in range(2)]
+        # both ranks hold the SAME reduced arena and the SAME parameters afterwards (bitwise: one all-reduce result, one AdamW)
+        assert torch.equal(got[0]["grads"], got[1]["grads"]), mode
+        for k in got[0]["params"]:
+            assert torch.equal(got[0]["params"][k], got[1]["params"][k]), (mode, k)
+        # per-shard BatchNorm: running statistics differ between the ranks (no collective besides the gradient all-reduce)
+        assert not torch.equal(got[0]["buffers"]["encoder_b.fc.1.running_mean"], got[1]["buffers"]["encoder_b.fc.1.running_mean"])
+        # reduced arena of the last step == the two shards summed in one process
+        g, w = got[0]["grads"].double(), want_g.double()
+        rel = float((g - w).norm() / w.norm())
+        tol = 2e-4 if prec == "fp32" else 2e-2               # bf16: atomics order -> a few bf16 roundings / ReLU flips over 4 steps
+        assert rel <= tol, (mode, rel)
+        # each rank's own loss of the last step == the restated shard's
+        last = [got[r]["losses"][-1] for r in range(2)]
+        np.testing.assert_allclose(last, want_losses[-1], rtol=1e-4 if prec == "fp32" else 3e-3)
+        # parameters after the last AdamW step
+        ref = dict(reps[0]["model"].named_parameters())
+        for k, p in got[0]["params"].items():
+            if k in CHAOTIC_BIASES:
+                continue
+            d = (p - ref[k].detach().cpu()).abs()
+            assert float(d.max()) <= 8 * 1e-3 and float(d.mean()) <= (2e-5 if prec == "fp32" else 2e-4), (mode, k, float(d.max()), float(d.mean()))
+        for r in range(2):                                   # per-shard BatchNorm buffers == the restated replica's
+            refb = dict(reps[r]["model"].named_buffers())
+            for k, v in got[r]["buffers"].items():
+                if v.dtype.is_floating_point:
+                    np.testing.assert_allclose(v.numpy(), refb[k].cpu().numpy(), rtol=2e-2, atol=2e-3, err_msg=f"{mode} {k}")
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent spawns the ranks before any GPU call, rank 0
+    prints the ONE JSON line, weak scaling (value counts both ranks' rows)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PYTHONPATH"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "4096",
+                          "--backend", "gloo", "--single-device", "--cpu-steps", "0", "--no-probe"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 8192 and j["config"]["parallelism"] == "dp2"
+    assert abs(j["value"] - 2 * 4096 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    # a failing rank ends the run with a non-zero status instead of leaving the others in the collective
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+                          "--backend", "gloo", "--cpu-steps", "0", "--no-probe"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=tmp_path)
+    assert bad.returncode != 0
+
+
+def test_trainer_under_two_ranks(tmp_path):
+    """train.py under two ranks for two epochs: the same number of steps on both, and every control-flow input (validation loss,
+    learning rate, early-stop counter) identical on both (all_ranks_mean / average_bn_buffers)."""
+    log = tmp_path / "log"
+    res = _run_ranks([os.path.join(ROOT, "vae-los-angeles_amd", "train.py"), "--samples", "16384", "--batch-size", "1024", "--epochs", "2",
+                      "--checkpoint-dir", str(tmp_path), "--backend", "gloo", "--single-device", "--log-json", str(log)], cwd=tmp_path)
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+    quiet = [l for l in res[1][1].splitlines() if l.strip() and not l.startswith("[Gloo]")]                  # gloo's own connection banner aside
+    assert "Epoch [2/2]" in res[0][1] and "Training complete" in res[0][1] and quiet == []                    # rank 0 alone prints
+    logs = [[json.loads(l) for l in open(f"{log}.rank{r}")] for r in range(2)]
+    assert len(logs[0]) == len(logs[1]) == 2
+    for e0, e1 in zip(*logs):
+        assert e0["steps"] == e1["steps"] == (16384 - int(16384 * 0.2)) // 2 // 1024
+        assert e0["val_loss"] == e1["val_loss"] and e0["lr"] == e1["lr"] and e0["trigger"] == e1["trigger"] and e0["best_val"] == e1["best_val"]
+        assert e0["train_loss"] != e1["train_loss"]          # different shards
+    assert logs[0][1]["train_loss"] < logs[0][0]["train_loss"]
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("best_multivae_")]) == 1                       # rank 0 alone writes

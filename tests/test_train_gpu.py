@@ -336,16 +336,16 @@ def test_graphed_data_parallel_step(tmp_path, overlap):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_scaled_omics_widths(prec):
-    """BASELINE configs[4] widths (RNA=20000, DNA=27000, latent=128) at a small batch: one step against the oracle
-    (generic K/N tail handling, 211-tile-wide dW grids, heads with N=256)."""
+    """BASELINE configs[4] widths (RNA=20000, DNA=27000, latent=128) at a small batch: one step against the oracle over ALL
+    outputs, loss terms, 39 gradients and BatchNorm buffers (generic K/N tail handling, 211-tile-wide dW grids, heads with N=256
+    and decoder stems that leave the grouped tiny-dW path).  fp32 mode against the reference arithmetic; bf16 mode against the
+    bf16-aware oracle at TOL_Q (pinned on the CPU by tests/test_oracle_q_vs_golden.py) and, loosely, against the fp64 oracle."""
+    from test_model_gpu import oracle_step, compare_step, tol_q, TOL, report
     A, D, S, L, E, B = 20000, 27000, 24, 128, 32, 192
     P, Bf = O.make_params(5, A, D, S, L, E)
     a, b, site = O.make_batch(6, B, A, D, S)
     masks, eps = O.make_noise(7, B, L)
     P64, Bf64 = f64(P), f64(Bf)
-    oa, ob, oc, mu, lv, cache = O.vae_forward(P64, Bf64, a.astype(np.float64), b.astype(np.float64), site, masks, eps.astype(np.float64), True)
-    tot, rec, cls, kld, g = O.vae_loss(oa, a.astype(np.float64), ob, b.astype(np.float64), oc, site, mu, lv)
-    G = O.vae_backward(P64, cache, g["recon_a"], g["recon_b"], g["recon_c"], g["mu"], g["logvar"])
     model = load_state(MultiModalVAE(A, D, S, L, embed_dim=E), P, Bf).to(DEV).set_precision(prec).train()
     ta, tb, ts = (torch.from_numpy(x).to(DEV) for x in (a, b, site))
     engine.GLOBAL_NOISE.inject(masks_list(masks), torch.from_numpy(eps))
@@ -353,10 +353,14 @@ def test_scaled_omics_widths(prec):
     loss, r_, c_, k_ = vae_loss(ra, ta, rb, tb, rc, ts, m_, l_)
     engine.GLOBAL_NOISE.clear()
     loss.backward()
-    tol_out, tol_loss, tol_fro = (1e-4, 2e-5, 2e-3) if prec == "fp32" else (3e-2, 3e-3, 0.25)
-    for got, want in ((ra, oa), (rb, ob), (m_, mu), (l_, lv)):
-        assert float(np.abs(got.detach().cpu().numpy() - want).max() / np.abs(want).max()) <= tol_out
-    assert abs(loss.item() - tot) <= tol_loss * abs(tot)
-    for k in ("encoder_b.fc.0.weight", "decoder_b.fc.4.weight", "encoder_a.fc_mu.weight", "decoder_a.fc.0.weight"):
-        gv = dict(model.named_parameters())[k].grad.cpu().numpy()
-        assert float(np.linalg.norm(gv - G[k]) / np.linalg.norm(G[k])) <= tol_fro, k
+    outs, losses = (ra, rb, rc, m_, l_), (loss.item(), r_, c_, k_)
+    ref = oracle_step(P64, Bf64, a, b, site, masks, eps, 1e-3, 1.0, None, None)
+    # K = 20 000 / 27 000 dot products accumulate 25-35x more fp32 rounding than the default widths: 2e-4 outputs (TOL: 5e-5)
+    e = compare_step(model, outs, losses, ref, dict(TOL[prec], out=2e-4, fro=2e-3) if prec == "fp32" else TOL[prec])
+    report(f"scaled widths 20000/27000/128 B={B} prec={prec} vs fp64 reference arithmetic: out {e['out']:.3e}; loss rel {e['loss']:.3e}; "
+           f"grad max scaled {e['grad']:.3e} ({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")
+    if prec == "bf16":
+        refq = oracle_step(P64, Bf64, a, b, site, masks, eps, 1e-3, 1.0, None, O.BF16)
+        e = compare_step(model, outs, losses, refq, tol_q(B))
+        report(f"scaled widths 20000/27000/128 B={B} prec=bf16 vs bf16-aware oracle:        out {e['out']:.3e}; loss rel {e['loss']:.3e}; "
+               f"grad max scaled {e['grad']:.3e} ({e['grad_worst']}); grad max Frobenius-rel {e['fro']:.3e} ({e['fro_worst']})")

@@ -47,6 +47,7 @@ class NoiseSource:
     def __init__(self):
         self._injected = None
         self._offsets = {}            # device -> int64[1] tensor (bit pattern of the uint64 Philox offset)
+        self.stream_rank = None       # None: torch.distributed's rank; an int: draw THAT rank's stream (single-process restatement of N ranks)
 
     def inject(self, masks, eps):
         self._injected = (list(masks), eps)
@@ -56,7 +57,9 @@ class NoiseSource:
 
     def _seed(self):
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self.stream_rank is not None:
+            seed = (seed + 0x9E3779B97F4A7C15 * (int(self.stream_rank) + 1)) & 0xFFFFFFFFFFFFFFFF
+        elif torch.distributed.is_available() and torch.distributed.is_initialized():
             seed = (seed + 0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1)) & 0xFFFFFFFFFFFFFFFF
         return seed
 

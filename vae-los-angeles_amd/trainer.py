@@ -78,6 +78,10 @@ def build_parser(kind):
     ap.add_argument("--resume", default=None, help="training state written by --save-state (model + optimiser + scheduler + noise)")
     ap.add_argument("--save-state", default=None, help="write a resumable training state here after every epoch")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python (reference-shaped loop) instead of the captured step")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend under torchrun (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank on cuda:0 (needs --backend gloo)")
+    ap.add_argument("--log-json", default=None, help="append one JSON object per epoch (steps, train/val loss, lr, early-stop counter) to "
+                                                     "<path>.rank<r>: every rank writes its own file, so that a run can be checked for identical decisions")
     return ap
 
 
@@ -109,11 +113,18 @@ def run(kind, argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("the trainers need an MI355X: the product path has no CPU fallback")
+    if args.single_device:
+        if args.backend == "nccl":
+            raise SystemExit("--single-device puts every rank on cuda:0, which RCCL refuses: use --backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     if args.data:
         tpm, beta_v, site = load_pickled_dataset(args.data)
@@ -217,6 +228,11 @@ def run(kind, argv=None):
         if rank == 0:
             print(f"Epoch [{epoch + 1}/{args.epochs}] | Train Loss: {running / max(steps, 1):.2f} | Val Loss: {val_loss:.2f} | "
                   f"beta={beta:.5f} | lr={optimizer.param_groups[0]['lr']:.2e} | {world * steps * B / dt:,.0f} samples/s")
+        if args.log_json:
+            import json
+            with open(f"{args.log_json}.rank{rank}", "a") as f:
+                f.write(json.dumps(dict(epoch=epoch + 1, steps=steps, train_loss=running / max(steps, 1), val_loss=val_loss,
+                                        lr=optimizer.param_groups[0]["lr"], best_val=min(best_val, val_loss), trigger=trigger)) + "\n")
         stop = False
         if val_loss < best_val:
             best_val, trigger = val_loss, 0
