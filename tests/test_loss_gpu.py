@@ -195,7 +195,7 @@ def test_reconstruction_loss_inside_the_decoder_gemms(B, weighted):
 @pytest.mark.parametrize("M,N,K,bce", [(1000, 782, 128, False), (777, 572, 512, True), (300, 333, 256, True), (4096, 128, 192, False)])
 def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
     """mmvae_gemm_nt with MMVAE_EPI_LOSS_MSE / MMVAE_EPI_LOSS_BCE_LOGIT against the pair it replaces (store epilogue -> fp32
-    output -> mmvae_vae_loss): bit-identical bf16 gradient rows incl. zeroed pad columns, loss sum to 1e-8; target rows 16-, 8- and
+    output -> mmvae_vae_loss): bit-identical bf16 gradient rows incl. zeroed pad columns, loss sum to 1e-7; target rows 16-, 8- and
     4-byte aligned (N = 572, 782, 333), ragged row and column tiles."""
     from mmvae.ops import PREC_BF16
     dev = "cuda"
@@ -219,7 +219,7 @@ def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
     k = 1 if bce else 0
     ops.gemm_nt(PREC_BF16, A, pl.w, N, K, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_BCE_LOGIT if bce else ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[k:k + 1])
     assert torch.equal(g_ref.view(torch.int16), g_new.view(torch.int16))
-    np.testing.assert_allclose(sums2[k].item(), sums[k].item(), rtol=1e-8)
+    np.testing.assert_allclose(sums2[k].item(), sums[k].item(), rtol=1e-7)       # same terms; the per-thread fp32 partial sums group them differently
     assert sums2[1 - k].item() == 0.0
     with pytest.raises(RuntimeError):                                             # one K step only: not this kernel's case
         ops.gemm_nt(PREC_BF16, A[:, :64].contiguous(), pl.w, N, 64, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[0:1])

@@ -90,6 +90,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+// Natural logarithm as ONE v_log_f32 (log2, about 1 ulp) and one multiply.  hipcc expands __logf / logf into 13 vector instructions
+// (denormal pre-scaling, a compensated multiply by ln 2, an inf / nan select): in the BCE term that was 22 of the 58 instructions per
+// element (round 3, read off the ISA).  Differs from logf only in the last bits and for denormal arguments (below 1.18e-38: -inf here,
+// i.e. torch's -100 clamp, where torch still has -87.3 .. -103): no sigmoid output of a finite logit above -87 is that small.
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -388,7 +388,7 @@ __device__ __forceinline__ float mse_part(const mmvae_loss_args& a, long tid0, l
 template <typename GT, int V, bool WRT_LOGIT>
 __device__ __forceinline__ float bce_part_g(const mmvae_loss_args& a, long tid0, long stride) {
     auto f = [](float pe, float te, float& g) {
-        const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
+        const float lp = fmaxf(fast_ln(pe), -100.f), l1p = fmaxf(fast_ln(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
         const float pq = (1.f - pe) * pe, d = pe - te;
         // torch: grad_p = (p - t) / max(p (1 - p), 1e-12); w.r.t. the logit that times p (1 - p): exactly (p - t) unless clamped
         if constexpr (WRT_LOGIT) g = pq >= 1e-12f ? d : d * pq * 1e12f;

@@ -136,7 +136,7 @@ struct EpiLoss {
         if constexpr (MODE == 0) { const float d = x - t; g = 2.f * d; return d * d; }
         else {
             const float pe = __builtin_amdgcn_rcpf(1.f + __expf(-x));
-            const float lp = fmaxf(__logf(pe), -100.f), l1p = fmaxf(__logf(1.f - pe), -100.f);
+            const float lp = fmaxf(fast_ln(pe), -100.f), l1p = fmaxf(fast_ln(1.f - pe), -100.f);
             const float pq = (1.f - pe) * pe, d = pe - t;
             g = pq >= 1e-12f ? d : d * pq * 1e12f;
             return -(t * lp + (1.f - t) * l1p);

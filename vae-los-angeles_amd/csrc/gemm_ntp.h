@@ -24,8 +24,9 @@
 // which is what bounds this kernel, not HBM and not the MFMA pipe.
 // The LDS images are the first generation's (128-byte rows = one K step of 64 bf16, 16-byte chunks XOR-ed with row & 7), so are
 // the swapped-operand MFMA order and the store layout of the epilogue (gemm_nt_epi.h).
-// BatchNorm statistics: per-lane sums over the lane's 4 rows, a wave-private transposition through 1 KB of LDS instead of the
-// 60-shuffle butterfly, accumulated per workgroup in LDS over ALL its tiles and added to the f64 accumulators once per workgroup
+// BatchNorm statistics: per-lane sums over the lane's 4 rows, a 15-add DPP reduce-scatter over the 16 lanes that hold the other rows
+// of the same columns (round 3; before: a wave-private transposition through 1 KB of LDS, 16 rounds per tile), kept in TWO registers
+// per lane over ALL tiles of the workgroup's column tile, then one LDS add per workgroup and one f64 atomic per column and workgroup
 // (256 adders per column instead of one per row tile).
 #pragma once
 #include "common.h"
@@ -59,7 +60,7 @@ template <int NT_, int WC_> struct NtpCfg {
     static constexpr int A_SLOT = BM * ROW_BYTES, W_SLOT = BN * ROW_BYTES;
     static constexpr int RA = 3, RW = 3;                      // ring slots: a step is produced two barriers before it is read
     static constexpr int OFF_W = RA * A_SLOT;
-    static constexpr int OFF_SCR = OFF_W + RW * W_SLOT;       // 1 KB per consumer wave: statistics transposition
+    static constexpr int OFF_SCR = OFF_W + RW * W_SLOT;       // 1 KB per consumer wave (spare: the statistics no longer pass through it)
     static constexpr int OFF_STAT = OFF_SCR + NCONS * 1024;   // [WR][2][BN] floats: the workgroup's running column sums
     static constexpr int OFF_ECOL = OFF_STAT + WR * 2 * BN * 4;
     static constexpr int TOTAL = OFF_ECOL + 2 * BN * 4;       // two copies of the per-column constants (tile parity): 158 KB (128 x 256), 104 KB (128 x 128)
@@ -102,6 +103,29 @@ __device__ __forceinline__ void ntp_wait_set(f32x4 (&s)[8]) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "n"(N) : "memory");
 }
 
+// Sum of v[i] over the 16 lanes of a DPP row, scattered: lane li (0..15 inside its row) returns the row's total of v[li].
+// Recursive halving with DPP moves (row_ror:8 = lane ^ 8; lane ^ 4 as row_ror:12 for the lanes of banks 0 / 2 and row_ror:4 for the
+// others -- row_ror:n makes lane i read lane (i - n) mod 16; quad_perm for lane ^ 2 and lane ^ 1): 15 adds instead of 60.
+template <int CTRL> __device__ __forceinline__ float ntp_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ntp_row16_reduce_scatter(const float (&v)[16], int li) {
+    const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float keep = b3 ? v[8 + j] : v[j], send = b3 ? v[j] : v[8 + j]; a[j] = keep + ntp_dpp<0x128>(send); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b2 ? a[4 + j] : a[j], send = b2 ? a[j] : a[4 + j];
+        const int lo = __builtin_amdgcn_mov_dpp(__float_as_int(send), 0x124, 0xf, 0xf, true);                  // from lane - 4 (lanes with bit 2 set)
+        b[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(lo, __float_as_int(send), 0x12C, 0xf, 0x5, false));   // banks 0, 2: from lane + 4
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const float keep = b1 ? b[2 + j] : b[j], send = b1 ? b[j] : b[2 + j]; c[j] = keep + ntp_dpp<0x4E>(send); }
+    const float keep = b0 ? c[1] : c[0], send = b0 ? c[0] : c[1];
+    return keep + ntp_dpp<0xB1>(send);
+}
+
 template <typename Cfg, typename AT, typename Epi>
 __global__ __launch_bounds__(64 * Cfg::NWAVES, Cfg::NWAVES / 4)
 void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
@@ -140,7 +164,6 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // ---------------------------------------------------------------------------------- MFMA consumers
         const int wr = wid / WC, wc = wid % WC;
         const int li = lane & 15, lg = lane >> 4;
-        float* scr = (float*)(smem + Cfg::OFF_SCR + wid * 1024);
         const bool want_stats = Epi::STATS && (epi.stat1 != nullptr || epi.stat2 != nullptr);
         for (int i = tid; i < Cfg::WR * 2 * BN; i += 64 * Cfg::NCONS) wgstat[i] = 0.f;     // ordered by the first barrier
         f32x4 acc[NH][4][4];
@@ -166,6 +189,16 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                     if (NTP_ABL == 3) asm volatile("" :: "v"(bf[n]), "v"(af[m]));
                     else Mma<CT>::mma(acc[nb][m][n], bf[n], af[m]);      // swapped operands (gemm_nt_epi.h)
                 }
+        };
+        float st_sum1 = 0.f, st_sum2 = 0.f;          // this lane's column (see the epilogue) over the tiles of the current column tile
+        auto dump_stats = [&]() __attribute__((always_inline)) {           // -> the workgroup's sums; every (wr, column) entry has ONE owner lane
+            if (want_stats) {
+                const int ln = ntp_lane_id(), li_ = ln & 15, lg_ = ln >> 4;
+                const int cl = wc * 16 * NT + 32 * (li_ >> 3) + 8 * lg_ + (li_ & 7);
+                wgstat[(wr * 2 + 0) * BN + cl] += st_sum1;
+                wgstat[(wr * 2 + 1) * BN + cl] += st_sum2;
+                st_sum1 = 0.f; st_sum2 = 0.f;
+            }
         };
         auto flush_stats = [&](int ct) __attribute__((always_inline)) {        // the workgroup's column sums -> the f64 accumulators; all consumers are past a barrier
             if (want_stats && tid < BN) {
@@ -249,26 +282,19 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                             *(uint4*)(cp + ld8) = uint4{st1[0], st1[1], st1[2], st1[3]};
                         }
                         if (Epi::STATS && want_stats) {
+                            // value 8 h + 2 qd + c of this lane = column cwb + 32 h + 8 lg + 2 qd + c, summed over the lane's 4 rows; the 16 lanes
+                            // of the DPP row (li = 0..15, one lg) hold the other rows of the same columns: lane li ends with the total of value li.
+                            // Kept in two registers over ALL tiles of the column tile (dump_stats), not per tile through LDS.
+                            static_assert(NH == 1, "statistics registers: one 64-column block per consumer wave");
+                            float v1[16], v2[16];
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                                for (int which = 0; which < 2; ++which)
+                                for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-                                    for (int e0 = 0; e0 < 8; e0 += 4) {
-                                        // image [lg][4 values][li] (1 KB) of four columns of one statistic; lane L < 16 adds the 16 floats of (lg', e) = (L / 4, L % 4)
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) scr[(lg * 4 + e) * 16 + li] = which ? s2[h][(e0 + e) >> 1][e & 1] : s1[h][(e0 + e) >> 1][e & 1];
-                                        __builtin_amdgcn_wave_barrier();
-                                        if (lane_e < 16) {
-                                            const f32x4* rp = (const f32x4*)(scr + lane_e * 16);
-                                            const f32x4 x0 = rp[0], x1 = rp[1], x2 = rp[2], x3 = rp[3];
-                                            const float tot = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3])) +
-                                                              ((x2[0] + x2[1]) + (x2[2] + x2[3])) + ((x3[0] + x3[1]) + (x3[2] + x3[3]));
-                                            float* dst = wgstat + (wr * 2 + which) * BN + cwb + 32 * h + 8 * (lane_e >> 2) + e0 + (lane_e & 3);     // this lane owns the entry
-                                            *dst += tot;
-                                        }
-                                        __builtin_amdgcn_wave_barrier();
-                                    }
+                                    for (int c = 0; c < 2; ++c) { v1[8 * h + 2 * qd + c] = s1[h][qd][c]; v2[8 * h + 2 * qd + c] = s2[h][qd][c]; }
+                            st_sum1 += ntp_row16_reduce_scatter(v1, li);
+                            st_sum2 += ntp_row16_reduce_scatter(v2, li);
                         }
                     }
                 };
@@ -277,7 +303,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                 else if (act == 0) fast(IntC<0>{}); else if (act == 1) fast(IntC<1>{}); else fast(IntC<2>{});
         };
         int T = T0, kt = 0, w3 = 0, a3 = 0, ct_prev = -1, ct_flush = -1, row0 = 0, col0 = 0, tpar = 0;
-        int e_row0 = 0, e_col0 = 0; const float* e_ecol = ecol2; bool e_pend = false;
+        int e_row0 = 0, e_col0 = 0; const float* e_ecol = ecol2; bool e_pend = false, e_dump = false;
 #ifdef MM_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
         NTP_T(t_begin);
@@ -292,6 +318,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
             if (e_pend) {
                 NTP_T(te0);
                 epilogue(e_row0, e_col0, e_ecol);
+                if (e_dump) dump_stats();
                 e_pend = false;
 #ifdef MM_STAMP
                 NTP_T(te1);
@@ -363,12 +390,15 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                 tpar ^= 1;
                 kt = 0;
                 T = next_tile(T);
+                e_dump = true;                      // the column tile's last row tile: the register sums go to the workgroup's sums
+                if (T >= 0) { int rt_, ct_; tile_rc(T, rt_, ct_); e_dump = ct_ != ct_prev; }
             }
         }
         ntp_bar();
         if (e_pend) {
             NTP_T(te0);
             epilogue(e_row0, e_col0, e_ecol);
+            dump_stats();
 #ifdef MM_STAMP
             NTP_T(te1);
             NTP_ACC(2, te1 - te0); NTP_ACC(4, 1);

@@ -436,7 +436,8 @@ class VAEGraph:
         if train:
             specs = [(2 * w, torch.float64) for w in widths_a + widths_b]
             nst = len(specs)
-            want_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list())
+            # decided by the caller (functional.run_graph) BEFORE it enters the autograd.Function, inside which grad mode is always off
+            want_bwd = bool(getattr(self, "_want_bwd", False)) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list()))
             if want_bwd:
                 specs += [(5, torch.float64), (5, torch.float32)] + self._grad_specs(xa is not None, xb is not None, site is not None)
             packed = zeros_pack(dev, specs)

@@ -98,7 +98,13 @@ def _participating(graph, saved, g_outs):
 def run_graph(graph, prec, train, xa, xb, site):
     """Forward of a VAEGraph with autograd wiring.  Returns (outs, mu, logvar)."""
     params = graph.param_list()
-    res = VAEGraphFn.apply(graph, prec, train, xa, xb, site, *params)
+    # a backward will follow: the forward's ONE memset then also zeroes the gradient arena, the backward's BatchNorm sums, the table
+    # gradient and the loss accumulators (3 fill launches per step -> 1)
+    graph._want_bwd = train and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    try:
+        res = VAEGraphFn.apply(graph, prec, train, xa, xb, site, *params)
+    finally:
+        graph._want_bwd = False
     n = len(graph.decoders)
     outs, mu, logvar = list(res[:n]), res[n], res[n + 1]
     saved = graph._last_saved
