@@ -168,32 +168,40 @@ __global__ __launch_bounds__(256) void embed_table_fwd_kernel(int S, int E, int 
     }
 }
 
+// All operands are a few KB: every workgroup first copies them into LDS in ONE round of independent loads (the table gradient summed
+// over its scatter copies in fixed order, the embedding, both head weights), then every thread forms its output element from LDS.
+// (Round 2's form walked w_mu / w_lv / emb in global memory inside the dot products: 20-24 dependent rounds of L2 latency, 22 us for
+// a few thousand multiply-adds.)
 __global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int L, const float* emb, const float* w_mu,
                                                                const float* w_lv, const float* dTc, int copies, float* d_emb, float* d_w_mu,
                                                                float* d_b_mu, float* d_w_lv, float* d_b_lv) {
     const int L2 = 2 * L;
-    extern __shared__ float dT[];                        // [S][2L]: the copies of the table gradient summed (fixed order)
+    extern __shared__ float sm[];
+    float* dT = sm;                                      // [S][2L]: the copies of the table gradient summed (fixed order)
+    float* sE = dT + S * L2;                             // [S][E]
+    float* sW = sE + S * E;                              // [2L][E]: w_mu rows, then w_lv rows
     for (int i = threadIdx.x; i < S * L2; i += blockDim.x) {
         float v = 0.f;
         for (int c = 0; c < copies; ++c) v += dTc[(long)c * S * L2 + i];
         dT[i] = v;
     }
+    for (int i = threadIdx.x; i < S * E; i += blockDim.x) sE[i] = emb[i];
+    for (int i = threadIdx.x; i < L2 * E; i += blockDim.x) sW[i] = i < L * E ? w_mu[i] : w_lv[i - L * E];
     __syncthreads();
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    // the three products are independent: one index space [dEmb | dWcat | db], so their (latency-bound) dot products of
-    // 20-24 terms run side by side instead of one phase after the other
+    // one index space [dEmb | dWcat | db]: the three products run side by side
     const int n0 = S * E, n1 = n0 + L2 * E, n2 = n1 + L2;
     for (int i = t0; i < n2; i += nt) {
         float acc = 0.f;
         if (i < n0) {                                    // dEmb = dT x Wcat
             const int s = i / E, e = i - s * E;
 #pragma unroll 4
-            for (int j = 0; j < L; ++j) acc += dT[s * L2 + j] * w_mu[(long)j * E + e] + dT[s * L2 + L + j] * w_lv[(long)j * E + e];
+            for (int j = 0; j < L2; ++j) acc += dT[s * L2 + j] * sW[j * E + e];
             d_emb[i] += acc;
         } else if (i < n1) {                             // dWcat = dT^T x emb
             const int k = i - n0, j = k / E, e = k - j * E;
 #pragma unroll 4
-            for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * emb[(long)s * E + e];
+            for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * sE[s * E + e];
             if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
         } else {
             const int j = i - n1;
@@ -747,8 +755,8 @@ extern "C" int mmvae_embed_table_bwd(int32_t S, int32_t E, int32_t L, const floa
                                      float* d_b_lv, void* stream) {
     if (S <= 0 || E <= 0 || L <= 0 || !emb || !w_mu || !w_lv || !d_table || !d_emb || !d_w_mu || !d_b_mu || !d_w_lv || !d_b_lv) return MMVAE_ERR_ARG;
     if (table_copies < 1) table_copies = 1;
-    const size_t lds = (size_t)S * 2 * L * sizeof(float);
-    if (lds > 48 * 1024) return MMVAE_ERR_ARG;
+    const size_t lds = ((size_t)S * 2 * L + (size_t)S * E + (size_t)2 * L * E) * sizeof(float);
+    if (lds > 64 * 1024) return MMVAE_ERR_ARG;                    // 60 KB at latent 128, embed 32, 24 sites
     const int work = S * E + 2 * L * E + 2 * L;          // one output element per thread
     hipLaunchKernelGGL(embed_table_bwd_kernel, dim3((work + 255) / 256), dim3(256), lds, (hipStream_t)stream, S, E, L, emb, w_mu, w_lv, d_table, table_copies, d_emb, d_w_mu, d_b_mu, d_w_lv, d_b_lv);
     MM_CHECK_LAUNCH();

@@ -2,6 +2,8 @@
 the owner of device memory and streams; all arithmetic happens in libmmvae_hip.so."""
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
