@@ -399,7 +399,7 @@ __device__ __forceinline__ float bce_part_g(const mmvae_loss_args& a, long tid0,
         const float lp = fmaxf(fast_ln(pe), -100.f), l1p = fmaxf(fast_ln(1.f - pe), -100.f);   // v_log_f32: 1 ulp, clamp as torch
         const float pq = (1.f - pe) * pe, d = pe - te;
         // torch: grad_p = (p - t) / max(p (1 - p), 1e-12); w.r.t. the logit that times p (1 - p): exactly (p - t) unless clamped
-        if constexpr (WRT_LOGIT) g = pq >= 1e-12f ? d : d * pq * 1e12f;
+        if constexpr (WRT_LOGIT) g = d * fminf(pq * 1e12f, 1.f);             // as EpiLoss::term (gemm_nt_epi.h): d * 1 is exact
         else g = d * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f));
         return -(te * lp + (1.f - te) * l1p);
     };

@@ -57,12 +57,23 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
     // ALL 16 target vectors of the thread are requested first (64 registers -- the accumulators die in the LDS image below): with 4
     // in flight per thread the pass ran at the latency-bound 3.6 TB/s of 32 KB in flight per CU; the LDS transposition now covers
     // their trip.  Branch-free clamped addresses (rows past M, columns past N are masked when used).
+    // Interior tiles (all but the last row / column tiles): no clamps on the target addresses, no bounds selects on the terms.
+    const bool interior = row0 + TILE <= M && col0 + 128 <= N;                      // workgroup-uniform
     float t[16][4];
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float* tp = T + (long)min(row0 + r0 + 8 * i, M - 1) * epi.ldt;
+        for (int i = 0; i < 16; ++i) {
+            const float* tp = T + (long)(row0 + r0 + 8 * i) * epi.ldt + colg;
 #pragma unroll
-        for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + min(colg + e, N - Epi::VT), &t[i][e]);
+            for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + e, &t[i][e]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float* tp = T + (long)min(row0 + r0 + 8 * i, M - 1) * epi.ldt;
+#pragma unroll
+            for (int e = 0; e < 4; e += Epi::VT) VLoad<float, Epi::VT>::ld(tp + min(colg + e, N - Epi::VT), &t[i][e]);
+        }
     }
     __syncthreads();                                               // every wave has finished reading the ring
 #pragma unroll
@@ -75,30 +86,43 @@ __device__ __forceinline__ void nt2_loss_epilogue(unsigned char* smem, const flo
     __syncthreads();
     const int gcols = (int)min((long)((N + 7) & ~7), epi.ldg);      // gradient columns that exist (pads are written as zeros)
     const unsigned char* src = smem + r0 * 512 + ((c ^ (r0 & 7)) << 4);     // (r0 + 8 i) & 7 == r0 & 7
-    float b4[4];
+    const f32x2 b01 = {ecol[4 * c], ecol[4 * c + 1]}, b23 = {ecol[4 * c + 2], ecol[4 * c + 3]};
+    f32x2 lsum2 = {0.f, 0.f};
+    if (interior) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) b4[e] = ecol[4 * c + e];
-    float lsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int grow = row0 + r0 + 8 * i;
-        const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
-        float g[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = grow < M && colg + e < N;
-            float ge;
-            const float l = epi.term(z[e] + b4[e], t[i][e], ge);
-            lsum += ok ? l : 0.f;
-            g[e] = ok ? ge : 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+            f32x2 g01, g23;
+            lsum2 += epi.term2(f32x2{z[0], z[1]} + b01, f32x2{t[i][0], t[i][1]}, g01);
+            lsum2 += epi.term2(f32x2{z[2], z[3]} + b23, f32x2{t[i][2], t[i][3]}, g23);
+            const bf16x4 o = {(bf16)g01[0], (bf16)g01[1], (bf16)g23[0], (bf16)g23[1]};
+            *(bf16x4*)(G + (long)(row0 + r0 + 8 * i) * epi.ldg + colg) = o;
         }
-        if (grow < M && colg < gcols) {
-            bf16x4 o;
+    } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)g[e];
-            *(bf16x4*)(G + (long)grow * epi.ldg + colg) = o;
+        for (int i = 0; i < 16; ++i) {
+            const int grow = row0 + r0 + 8 * i;
+            const f32x4 z = *(const f32x4*)(src + i * 8 * 512);
+            f32x2 g01, g23;
+            const f32x2 l01 = epi.term2(f32x2{z[0], z[1]} + b01, f32x2{t[i][0], t[i][1]}, g01);
+            const f32x2 l23 = epi.term2(f32x2{z[2], z[3]} + b23, f32x2{t[i][2], t[i][3]}, g23);
+            const float l[4] = {l01[0], l01[1], l23[0], l23[1]}, ge[4] = {g01[0], g01[1], g23[0], g23[1]};
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = grow < M && colg + e < N;
+                lsum2[e & 1] += ok ? l[e] : 0.f;
+                g[e] = ok ? ge[e] : 0.f;
+            }
+            if (grow < M && colg < gcols) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)g[e];
+                *(bf16x4*)(G + (long)grow * epi.ldg + colg) = o;
+            }
         }
     }
+    const float lsum = lsum2[0] + lsum2[1];
     const float ws = wave_sum(lsum);
     if (lane == 0) red[tid >> 6] = ws;
     __syncthreads();                                               // also: everybody is done with the LDS tile

@@ -138,8 +138,28 @@ struct EpiLoss {
             const float pe = __builtin_amdgcn_rcpf(1.f + __expf(-x));
             const float lp = fmaxf(fast_ln(pe), -100.f), l1p = fmaxf(fast_ln(1.f - pe), -100.f);
             const float pq = (1.f - pe) * pe, d = pe - t;
-            g = pq >= 1e-12f ? d : d * pq * 1e12f;
+            g = d * fminf(pq * 1e12f, 1.f);            // (p - t) unless p (1 - p) < 1e-12 (torch divides by max(p (1 - p), 1e-12)): d * 1 is exact
             return -(t * lp + (1.f - t) * l1p);
+        }
+    }
+    // Two adjacent elements at once: the additions and multiplications as packed f32 pairs (v_pk_add_f32 / v_pk_mul_f32 /
+    // v_pk_fma_f32: one issue slot for two elements -- the epilogue is bound by a single wave's instruction issue), transcendentals
+    // and clamps per element.  Per element the SAME operations on the same values as term(): bit-identical gradients.  Returns the two
+    // loss terms (the caller adds them up as pairs).
+    __device__ __forceinline__ f32x2 term2(const f32x2 x, const f32x2 t, f32x2& g) const {
+        if constexpr (MODE == 0) { const f32x2 d = x - t; g = d * 2.f; return d * d; }
+        else {
+            const f32x2 nx = x * -1.4426950408889634f;                     // __expf(-x) = exp2(-x log2 e)
+            const f32x2 s = f32x2{__builtin_amdgcn_exp2f(nx[0]), __builtin_amdgcn_exp2f(nx[1])} + 1.f;
+            const f32x2 pe = {__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
+            const f32x2 om = 1.f - pe;
+            f32x2 lp = f32x2{__builtin_amdgcn_logf(pe[0]), __builtin_amdgcn_logf(pe[1])} * 0.6931471805599453f;
+            f32x2 l1p = f32x2{__builtin_amdgcn_logf(om[0]), __builtin_amdgcn_logf(om[1])} * 0.6931471805599453f;
+            lp = f32x2{fmaxf(lp[0], -100.f), fmaxf(lp[1], -100.f)};
+            l1p = f32x2{fmaxf(l1p[0], -100.f), fmaxf(l1p[1], -100.f)};
+            const f32x2 pq = om * pe, d = pe - t, c = pq * 1e12f;
+            g = d * f32x2{fminf(c[0], 1.f), fminf(c[1], 1.f)};
+            return -__builtin_elementwise_fma(1.f - t, l1p, t * lp);
         }
     }
 };
