@@ -116,7 +116,7 @@ def test_two_ranks_through_the_hip_engine(tmp_path, prec):
         # reduced arena of the last step == the two shards summed in one process
         g, w = got[0]["grads"].double(), want_g.double()
         rel = float((g - w).norm() / w.norm())
-        tol = 2e-4 if prec == "fp32" else 2e-2               # bf16: atomics order -> a few bf16 roundings / ReLU flips over 4 steps
+        tol = 1e-3 if prec == "fp32" else 2e-2               # four steps: atomics order, then Adam on gradients that are rounding noise; bf16 also ReLU flips
         assert rel <= tol, (mode, rel)
         # each rank's own loss of the last step == the restated shard's
         last = [got[r]["losses"][-1] for r in range(2)]
