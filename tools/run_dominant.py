@@ -31,12 +31,13 @@ elif tag == "EncoderB.L0.dW":          # dW[512,572] += dy^T b with dy = BatchNo
     dw, db = torch.zeros(512, 572, device=dev), torch.zeros(512, device=dev)
     slab = torch.empty(1 << 24, device=dev)
     run = lambda i: ops.gemm_tn(PREC_BF16, P[i % nbuf], Q[i % nbuf], dw, db, 512, 572, p_prologue=(Y[i % nbuf], mean, rstd, coef), slab=slab)
-elif tag == "EncoderB.L0.fwd":         # y[B,512] = b W^T (+ BN statistics)
-    A = [torch.rand(M, 572, device=dev) for _ in range(nbuf)]
-    W = torch.randn(512, 572, device=dev) / 24; bias = torch.zeros(512, device=dev)
+elif tag in ("EncoderB.L0.fwd", "EncoderA.L0.fwd"):   # y[B,512] = b W^T / y[B,128] = a W^T (+ BN statistics): the north_star's named GEMMs
+    N, K = (512, 572) if tag == "EncoderB.L0.fwd" else (128, 782)
+    A = [torch.rand(M, K, device=dev) for _ in range(nbuf)]
+    W = torch.randn(N, K, device=dev) / K ** 0.5; bias = torch.zeros(N, device=dev)
     pl = ops.PreparedLinear([W], [bias], PREC_BF16, dev); ops.WeightPrep([pl], dev).run()
-    out = torch.empty(M, 512, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, 512, dtype=torch.float64, device=dev)
-    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, 512, 572, out, bias=pl.bias, stats=st)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev); st = torch.zeros(2, N, dtype=torch.float64, device=dev)
+    run = lambda i: ops.gemm_nt(PREC_BF16, A[i % nbuf], pl.w, N, K, out, bias=pl.bias, stats=st)
 elif tag in ("DecoderB.L2.fwd", "DecoderA.L1.fwd"):   # the decoders' last layers as the training step runs them: reconstruction loss in the epilogue
     N, K, bce = (572, 512, True) if tag == "DecoderB.L2.fwd" else (782, 128, False)
     A = bf(M, K)
