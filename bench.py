@@ -167,6 +167,11 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the GPU yet
         # (torch is imported, no HIP call was made) and never will: it only waits for its children.
         raise SystemExit(spawn_ranks(args.gpus))
+    # stdout carries ONE line, the JSON: everything else a library prints there (RCCL writes a five-line version banner to stdout when
+    # its communicator is created) is sent to stderr by pointing file descriptor 1 at it until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -389,7 +394,8 @@ def main():
                               for kk in kernels[:40]]
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_steps)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
