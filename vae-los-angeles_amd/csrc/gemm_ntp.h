@@ -57,6 +57,9 @@ template <int NT_, int WC_> struct NtpCfg {
     static constexpr int NH = NT / 4;                         // 64-column blocks per consumer wave
     static constexpr int BM = 64 * WR, BN = 16 * NT * WC;
     static constexpr int NCONS = WR * WC, NPA = 4, NWAVES = NCONS + NPA;
+    // who issues the W tile's LDS-DMA: the consumer waves at 128 x 128 (one per SIMD, idle for two thirds of a K step: EncoderA.L0.fwd
+    // 55.4 -> 51.7 us, same box), the producers at 128 x 256 (two consumers per SIMD at 166 registers: 71.6 against 75.7 us)
+    static constexpr bool WCONS = WC_ == 2;
     static constexpr int A_SLOT = BM * ROW_BYTES, W_SLOT = BN * ROW_BYTES;
     static constexpr int RA = 3, RW = 3;                      // ring slots: a step is produced two barriers before it is read
     static constexpr int OFF_W = RA * A_SLOT;
@@ -159,6 +162,32 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     { int rt, ct; tile_rc(T0, rt, ct); if (rt >= gx) return; }
     int G = 0;                                                      // K steps of this workgroup over all its tiles
     for (int T = T0; T >= 0; T = next_tile(T)) G += nk;
+
+    // W: the issuing waves' WPW pieces (8 LDS rows each) of the column tile per K step.  LDS row x of the tile's W block holds W row
+    // (x & ~63) + EpiCols::wrow(x & 63) (the epilogue's column order), chunk (position ^ (x & 7)): a part per wave (scalar), a
+    // compile-time part per piece (scalar multiply) and a lane part in ONE VGPR.  Issued by the consumer waves or by the producers (NtpCfg::WCONS).
+    constexpr bool WCONS = Cfg::WCONS;
+    constexpr int WPW = BN / 8 / (WCONS ? Cfg::NCONS : Cfg::NPA);      // pieces per issuing wave and K step: 4 / 4 (consumers), 8 / 4 (producers)
+    constexpr bool PAIRC = EC::G == 8;
+    const int widx = WCONS ? wid : wid - Cfg::NCONS;                   // this wave's index among the issuing waves (the other role never issues)
+    const int p0 = widx * WPW;
+    const int wrow_wave = PAIRC ? (p0 >> 3) * 64 + 32 * ((p0 & 7) >> 2) : 8 * p0;
+    auto wrow_piece = [](int i) constexpr { return PAIRC ? 32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1) : 8 * i; };
+    const unsigned wlds0 = lds_addr_of(smem) + Cfg::OFF_W + p0 * 1024;
+    int wT = T0, wkt = 0, wcol0, wslot = 0; { int rt, ct; tile_rc(T0, rt, ct); wcol0 = ct * BN; }
+    auto issue_w = [&]() __attribute__((always_inline)) {           // DMA of the next W step into its ring slot (past the last step: the last one again)
+        const int ln = ntp_lane_id(), l3 = ln >> 3;
+        const unsigned wlane = ((unsigned)(PAIRC ? 8 * (l3 >> 2) + (l3 & 3) : l3) * (unsigned)ldw + (unsigned)(((ln & 7) ^ l3) * 8)) * 2u;
+        const bf16* sb = W + ((long)(wcol0 + wrow_wave) * ldw + (NTP_ABL == 1 ? 0 : wkt * 64));
+        const unsigned ls = wlds0 + wslot * Cfg::W_SLOT;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) ntp_dma16(sb + (long)wrow_piece(i) * ldw, wlane, ls, i * 1024);
+        wslot = wslot == Cfg::RW - 1 ? 0 : wslot + 1;
+        if (wkt + 1 < nk) { ++wkt; return; }
+        const int Tn = next_tile(wT);
+        if (Tn < 0) return;
+        wT = Tn; wkt = 0; int rt, ct; tile_rc(Tn, rt, ct); wcol0 = ct * BN;
+    };
 
     if (wid < Cfg::NCONS) {
         // ---------------------------------------------------------------------------------- MFMA consumers
@@ -308,8 +337,12 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
         NTP_T(t_begin);
 #endif
+        if (WCONS) { issue_w(); issue_w(); }                  // W of steps 0 and 1
         for (int g = 0; g < G; ++g) {
             NTP_T(tb0);
+            // own share of W(g) has landed: everything but the WPW youngest operations (= W(g+1)); this also retires the stores of the
+            // epilogue that ran one iteration ago
+            if (WCONS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPW) : "memory");
             ntp_bar();
 #ifdef MM_STAMP
             unsigned long long tb1 = __builtin_readcyclecounter();
@@ -343,6 +376,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                 // pending, its wait lands in the K step's common code as a vmcnt(0) in front of the first fragment read of EVERY step
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
             }
+            if (WCONS) issue_w();                                 // W(g+2) into the slot every consumer left one barrier ago; in flight across two barriers
             {
                 const int ln = ntp_lane_id(), li_ = ln & 15, lg_ = ln >> 4;
                 sw0 = (lg_ ^ (li_ & 7)) << 4; sw1 = ((4 + lg_) ^ (li_ & 7)) << 4;
@@ -404,6 +438,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
             NTP_ACC(2, te1 - te0); NTP_ACC(4, 1);
 #endif
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the W pieces issued past the last step have landed: no DMA outlives the workgroup
         ntp_bar();                                   // every consumer has added its last tile's column sums
         flush_stats(ct_prev);
 #ifdef MM_STAMP
@@ -460,29 +495,6 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
 #pragma unroll
             for (int i = 0; i < AI; ++i) ntp_ld16(s[i], voff[i] + ko, sbase);
         };
-        // W: this wave's WPW pieces (8 LDS rows each) of the column tile per K step.  LDS row x of the tile's W block holds W row
-        // (x & ~63) + EpiCols::wrow(x & 63) (the epilogue's column order), chunk (position ^ (x & 7)): a part per wave (scalar), a
-        // compile-time part per piece (scalar multiply) and a lane part in ONE VGPR
-        constexpr int WPW = BN / 8 / Cfg::NPA;                         // 8 (BN = 256) / 4 (BN = 128)
-        constexpr bool PAIRC = EC::G == 8;
-        const int l3 = lane >> 3;
-        const unsigned wlane = ((unsigned)(PAIRC ? 8 * (l3 >> 2) + (l3 & 3) : l3) * (unsigned)ldw + (unsigned)(((lane & 7) ^ l3) * 8)) * 2u;
-        const int p0 = pw * (BN / 8 / Cfg::NPA);
-        const int wrow_wave = PAIRC ? (p0 >> 3) * 64 + 32 * ((p0 & 7) >> 2) : 8 * p0;
-        auto wrow_piece = [](int i) constexpr { return PAIRC ? 32 * (i >> 2) + 16 * (i & 1) + 4 * ((i >> 1) & 1) : 8 * i; };
-        const unsigned wlds0 = lds_addr_of(smem) + Cfg::OFF_W + p0 * 1024;
-        int wT = T0, wkt = 0, wcol0, wslot = 0; { int rt, ct; tile_rc(T0, rt, ct); wcol0 = ct * BN; }
-        auto issue_w = [&]() __attribute__((always_inline)) {           // DMA of the next W step into its ring slot (past the last step: the last one again)
-            const bf16* sb = W + ((long)(wcol0 + wrow_wave) * ldw + (NTP_ABL == 1 ? 0 : wkt * 64));
-            const unsigned ls = wlds0 + wslot * Cfg::W_SLOT;
-#pragma unroll
-            for (int i = 0; i < WPW; ++i) ntp_dma16(sb + (long)wrow_piece(i) * ldw, wlane, ls, i * 1024);
-            wslot = wslot == Cfg::RW - 1 ? 0 : wslot + 1;
-            if (wkt + 1 < nk) { ++wkt; return; }
-            const int Tn = next_tile(wT);
-            if (Tn < 0) return;
-            wT = Tn; wkt = 0; int rt, ct; tile_rc(Tn, rt, ct); wcol0 = ct * BN;
-        };
 #ifdef MM_STAMP
         unsigned long long stmp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stprev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -523,8 +535,9 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // on it).  Measured and dropped: the W DMA in the consumer waves with 4-6 deep A sets; odd producer waves issuing
         // before they stage; a raised producer priority (twice as slow); nt / sc1 loads of A.
         constexpr int SETS = 3;
-        constexpr int N_SET = (SETS - 1) * AI + 2 * WPW;              // operations younger than the loads of the set that is staged next
-        constexpr int N_W = 2 * AI + WPW;                             // operations younger than the W pieces of the next step
+        constexpr int PW = WCONS ? 0 : WPW;                           // W pieces in this wave's queue per K step
+        constexpr int N_SET = (SETS - 1) * AI + 2 * PW;               // operations younger than the loads of the set that is staged next
+        constexpr int N_W = 2 * AI + PW;                              // operations younger than the W pieces of the next step
 #ifdef MM_STAMP
         // s_memtime at 8 points of an iteration, collected WITHOUT waiting (ntp_bar()'s lgkmcnt(0) retires them): a waiting stamp would
         // serialise the LDS writes and the issue streams it is supposed to time
@@ -543,10 +556,10 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         f32x4 S[SETS][AI];
 #pragma unroll
         for (int u = 0; u < SETS; ++u) { load(S[u]); adv(); }
-        issue_w(); issue_w();
+        if (!WCONS) { issue_w(); issue_w(); }
         ntp_wait_set<N_SET>(S[0]); stage(S[0]); load(S[0]); adv();
         ntp_wait_set<N_SET>(S[1]); if (staged < G) stage(S[1]); load(S[1]); adv();
-        NTP_WAITW(N_W)
+        if (!WCONS) { NTP_WAITW(N_W) }
         while (!done) {             // step g+2 comes from set (g + 2) % SETS: the index is a compile-time constant in the unrolled body
 #pragma unroll
             for (int u = 0; u < SETS; ++u) {
@@ -554,9 +567,9 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                 if (++g == G) { done = true; break; }
                 ntp_wait_set<N_SET>(S[(u + 2) % SETS]); NTP_ST(2);
                 if (staged < G) stage(S[(u + 2) % SETS]);
-                NTP_ST(4); issue_w(); NTP_ST(5);
+                NTP_ST(4); if (!WCONS) issue_w(); NTP_ST(5);
                 load(S[(u + 2) % SETS]); adv(); NTP_ST(6);
-                NTP_WAITW(N_W)
+                if (!WCONS) { NTP_WAITW(N_W) }
                 NTP_ST(7); NTP_STEND();
             }
         }
