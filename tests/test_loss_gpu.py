@@ -192,7 +192,10 @@ def test_reconstruction_loss_inside_the_decoder_gemms(B, weighted):
         step(True, tb=b.clone())
 
 
-@pytest.mark.parametrize("M,N,K,bce", [(1000, 782, 128, False), (777, 572, 512, True), (300, 333, 256, True), (4096, 128, 192, False)])
+@pytest.mark.parametrize("M,N,K,bce", [(1000, 782, 128, False), (777, 572, 512, True), (300, 333, 256, True), (4096, 128, 192, False),
+                                       # >= 16 384 rows, >= 8 K steps, 16-byte target rows: the software-pipelined kernel (gemm_nt2x.h) -- ragged last row
+                                       # tile (16 640 = 65 x 256), ragged last column tile (572, 332), 8 / 10 / 9 K steps
+                                       (16640, 572, 512, True), (16384, 332, 600, False), (32768, 128, 576, True)])
 def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
     """mmvae_gemm_nt with MMVAE_EPI_LOSS_MSE / MMVAE_EPI_LOSS_BCE_LOGIT against the pair it replaces (store epilogue -> fp32
     output -> mmvae_vae_loss): bit-identical bf16 gradient rows incl. zeroed pad columns, loss sum to 1e-7; target rows 16-, 8- and
