@@ -542,3 +542,40 @@ def test_ntp_matches_tile_kernels(M, N, K, lda, stats, act):
         np.testing.assert_allclose(res[1][1].cpu(), res[0][1].cpu(), rtol=2e-6, atol=1e-3)
         np.testing.assert_allclose(res[1][1][0].cpu(), got.sum(0).cpu(), rtol=1e-5, atol=1e-2)
         np.testing.assert_allclose(res[1][1][1].cpu(), (got ** 2).sum(0).cpu(), rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K,masked,stats", [(1024, 256, 512, True, True),      # EncoderB's second Linear (encoders.py:35) behind BN + ReLU + Dropout
+                                                (512, 128, 256, True, False),      # 128 x 128 tiles
+                                                (768, 256, 128, False, True)])     # eval mode: no dropout mask
+def test_ntp_prologue_matches_tile_kernels(M, N, K, masked, stats):
+    """gemm_ntp.h with the producers' BatchNorm + ReLU + Dropout operand prologue (bf16 A) against the register-staged tile kernel with
+    the same prologue (SrcBnReluDrop): same per-element arithmetic and MFMA order -> bit-identical bf16 outputs; and against fp64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    scale = (torch.rand(K, generator=g) + 0.5).to(DEV); shift = (torch.randn(K, generator=g) * 0.3).to(DEV)
+    mask = (torch.rand(M, K, generator=g) > 0.1).to(torch.uint8).to(DEV) if masked else None
+    inv_keep = 1.0 / 0.9 if masked else 1.0
+    W = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pl = _prep(W, b, PREC_BF16)
+    res = {}
+    try:
+        _set_tuning(9, 256)
+        for on in (0, 1):
+            _set_tuning(8, on)
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+            st = torch.zeros(2, N, dtype=torch.float64, device=DEV) if stats else None
+            ops.gemm_nt(PREC_BF16, Y, pl.w, N, K, out, bias=pl.bias, prologue=(scale, shift, mask, inv_keep), stats=st)
+            torch.cuda.synchronize()
+            res[on] = (out.clone(), None if st is None else st.clone())
+    finally:
+        _set_tuning(8, 1); _set_tuning(9, 16384)
+    h = torch.relu(Y.double() * (scale * inv_keep).double() + (shift * inv_keep).double())
+    if masked:
+        h = h * mask.double()
+    ref = h.to(torch.float32).to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t() + b.double()
+    got = res[1][0].double()
+    assert float((got - ref).abs().max()) <= _tol(K, float(ref.abs().max()), True) + 2e-2 * float(ref.abs().max())      # + the prologue's bf16 rounding
+    assert torch.equal(res[0][0], res[1][0])
+    if stats:
+        np.testing.assert_allclose(res[1][1].cpu(), res[0][1].cpu(), rtol=2e-6, atol=1e-3)

@@ -129,9 +129,30 @@ __device__ __forceinline__ float ntp_row16_reduce_scatter(const float (&v)[16], 
     return keep + ntp_dpp<0xB1>(send);
 }
 
-template <typename Cfg, typename AT, typename Epi>
+// Operand prologue of the producers (bf16 A only): A' = relu(A * scale[k] + shift[k]) * inv_keep * keep[row][k] -- BatchNorm-normalise +
+// ReLU + Dropout of the previous layer applied on the way into LDS (reference src/models/encoders.py:32-38 in front of the second
+// nn.Linear of EncoderB, :35).  The same arithmetic as SrcBnReluDrop (gemm_src.h): scale and shift pre-multiplied by inv_keep in an LDS
+// table, keep bytes as floats.  MASK = false: eval mode (no dropout).  K % 64 == 0, K <= 512.
+struct NtpProNone { static constexpr bool ON = false, MASK = false; };
+template <bool MASK_> struct NtpProBn {
+    static constexpr bool ON = true, MASK = MASK_;
+    const float* scale; const float* shift; const uint8_t* mask; long ldm; float inv_keep;
+};
+__device__ __forceinline__ void ntp_ld8(f32x2& d, unsigned voff, const void* sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ntp_wait_set(f32x4 (&s)[4], f32x2 (&m)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ntp_wait_set(f32x4 (&s)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]) : "n"(N) : "memory");
+}
+
+template <typename Cfg, typename AT, typename Epi, typename Pro = NtpProNone>
 __global__ __launch_bounds__(64 * Cfg::NWAVES, Cfg::NWAVES / 4)
-void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi)
+void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict__ W, long ldw, int M, int N, int K, int gx, int gy, Epi epi, Pro pro)
 {
     typedef bf16 CT;
     typedef Mma<CT>::frag frag;
@@ -139,8 +160,11 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     typedef EpiCols<sizeof(OT) == 2> EC;
     constexpr int NT = Cfg::NT, NH = Cfg::NH, BM = Cfg::BM, BN = Cfg::BN, WC = Cfg::WC;
     constexpr bool AF = sizeof(AT) == 4;
+    constexpr bool PRO = Pro::ON, PMASK = Pro::MASK;
+    static_assert(!PRO || !AF, "the operand prologue is for bf16 A");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* wgstat = (float*)(smem + Cfg::OFF_STAT);
+    float* const paux = (float*)(smem + Cfg::OFF_SCR);          // PRO: [2][512] floats -- scale * inv_keep, shift * inv_keep
     float* const ecol2 = (float*)(smem + Cfg::OFF_ECOL);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,6 +187,10 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     int G = 0;                                                      // K steps of this workgroup over all its tiles
     for (int T = T0; T >= 0; T = next_tile(T)) G += nk;
 
+    if constexpr (PRO) {
+        for (int i = tid; i < K; i += 64 * Cfg::NWAVES) { paux[i] = pro.scale[i] * pro.inv_keep; paux[512 + i] = pro.shift[i] * pro.inv_keep; }
+        __syncthreads();                                  // the producers stage their first K steps in front of the loop's first barrier
+    }
     // W: the issuing waves' WPW pieces (8 LDS rows each) of the column tile per K step.  LDS row x of the tile's W block holds W row
     // (x & ~63) + EpiCols::wrow(x & 63) (the epilogue's column order), chunk (position ^ (x & 7)): a part per wave (scalar), a
     // compile-time part per piece (scalar multiply) and a lane part in ONE VGPR.  Issued by the consumer waves or by the producers (NtpCfg::WCONS).
@@ -471,12 +499,13 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // its end -- then it re-reads the tile's first rows (finite data for rows that are never stored)
         struct It { int T, kt, row0; };
         It it; it.T = T0; it.kt = 0; { int rt, ct; tile_rc(T0, rt, ct); it.row0 = rt * BM; }
-        unsigned voff[AI];
+        unsigned voff[AI], moff[PMASK ? AI : 1];
         auto set_voff = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int rl = prow0 + RPI * i;                      // wave-uniform
                 voff[i] = ((unsigned)((it.row0 + rl < M ? rl : 0) + rsub) * (unsigned)lda + (unsigned)(q * EL)) * (unsigned)sizeof(AT);
+                if constexpr (PMASK) moff[i] = (unsigned)((it.row0 + rl < M ? rl : 0) + rsub) * (unsigned)pro.ldm + (unsigned)(q * EL);     // one keep byte per element
             }
         };
         set_voff();
@@ -494,6 +523,13 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
             const char* sbase = (const char*)A + (size_t)(NTP_ABL == 2 ? (blockIdx.x & 7) * BM : it.row0) * (size_t)lda * sizeof(AT);
 #pragma unroll
             for (int i = 0; i < AI; ++i) ntp_ld16(s[i], voff[i] + ko, sbase);
+        };
+        auto load_mask = [&](f32x2 (&m)[PMASK ? AI : 1], int kt_, int row0_) __attribute__((always_inline)) {      // the keep bytes of the same rows and K step
+            if constexpr (PMASK) {
+                const char* mbase = (const char*)pro.mask + (size_t)row0_ * (size_t)pro.ldm;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) ntp_ld8(m[i], moff[i] + (unsigned)(kt_ * 64), mbase);
+            }
         };
 #ifdef MM_STAMP
         unsigned long long stmp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stprev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -528,6 +564,33 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                 else *(f32x4*)(sA + r * ROW_BYTES + ((q ^ (r & 7)) << 4)) = s[i];
             }
         };
+        // PRO: the lane's 8 elements of every row are columns 64 kt + 8 q .. + 7 -- one set of 8 (scale, shift) pairs per K step
+        auto stage_pro = [&](f32x4 (&s)[AI], f32x2 (&ms)[PMASK ? AI : 1]) __attribute__((always_inline)) {
+            unsigned char* sA = smem + sslot * Cfg::A_SLOT;
+            const float* ap = paux + skt * 64 + 8 * q;
+            const f32x4 sc0 = *(const f32x4*)ap, sc1 = *(const f32x4*)(ap + 4), sh0 = *(const f32x4*)(ap + 512), sh1 = *(const f32x4*)(ap + 516);
+            skt = skt + 1 == nk ? 0 : skt + 1;
+            sslot = sslot == Cfg::RA - 1 ? 0 : sslot + 1;
+            ++staged;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int r = prow0 + RPI * i + rsub;
+                const uint4 u = __builtin_bit_cast(uint4, s[i]);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+                uint32_t mk[2] = {0x01010101u, 0x01010101u};
+                if constexpr (PMASK) { const uint2 m2 = __builtin_bit_cast(uint2, ms[i]); mk[0] = m2.x; mk[1] = m2.y; }
+                typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+                bf16x8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+                    const float sc = e < 4 ? sc0[e] : sc1[e - 4], sh = e < 4 ? sh0[e] : sh1[e - 4];
+                    const float v = fmaxf(x * sc + sh, 0.f);
+                    o[e] = (bf16)(v * (float)((mk[e >> 2] >> (8 * (e & 3))) & 0xffu));
+                }
+                *(bf16x8_t*)(sA + r * ROW_BYTES + ((q ^ (r & 7)) << 4)) = o;
+            }
+        };
         // One in-order queue per wave: per iteration g it takes [W(g+2) x WPW, A(g+2+SETS) x AI].  Before barrier g+1 the W of step g+1
         // (issued one iteration earlier) must have landed: everything but the 2 AI + WPW youngest operations -- which also completes every
         // A load issued before iteration g-1, so two A sets stay in flight across a barrier and a third one while its step is staged:
@@ -536,8 +599,9 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         // before they stage; a raised producer priority (twice as slow); nt / sc1 loads of A.
         constexpr int SETS = 3;
         constexpr int PW = WCONS ? 0 : WPW;                           // W pieces in this wave's queue per K step
-        constexpr int N_SET = (SETS - 1) * AI + 2 * PW;               // operations younger than the loads of the set that is staged next
-        constexpr int N_W = 2 * AI + PW;                              // operations younger than the W pieces of the next step
+        constexpr int LPS = AI * (PMASK ? 2 : 1);                     // loads per set: A pieces (+ keep-byte pieces)
+        constexpr int N_SET = (SETS - 1) * LPS + 2 * PW;              // operations younger than the loads of the set that is staged next
+        constexpr int N_W = 2 * LPS + PW;                             // operations younger than the W pieces of the next step
 #ifdef MM_STAMP
         // s_memtime at 8 points of an iteration, collected WITHOUT waiting (ntp_bar()'s lgkmcnt(0) retires them): a waiting stamp would
         // serialise the LDS writes and the issue streams it is supposed to time
@@ -554,21 +618,27 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         int g = 0;
         bool done = false;
         f32x4 S[SETS][AI];
+        f32x2 MS[SETS][PMASK ? AI : 1];
+        auto loadset = [&](int u) __attribute__((always_inline)) { const int kt_ = it.kt, r0_ = it.row0; load(S[u]); load_mask(MS[u], kt_, r0_); adv(); };
+        auto waitset = [&](int u) __attribute__((always_inline)) {       // u is a constant after unrolling, as in S[u]
+            if constexpr (PMASK) ntp_wait_set<N_SET>(S[u], MS[u]); else ntp_wait_set<N_SET>(S[u]);
+        };
+        auto stageset = [&](int u) __attribute__((always_inline)) { if constexpr (PRO) stage_pro(S[u], MS[u]); else stage(S[u]); };
 #pragma unroll
-        for (int u = 0; u < SETS; ++u) { load(S[u]); adv(); }
+        for (int u = 0; u < SETS; ++u) loadset(u);
         if (!WCONS) { issue_w(); issue_w(); }
-        ntp_wait_set<N_SET>(S[0]); stage(S[0]); load(S[0]); adv();
-        ntp_wait_set<N_SET>(S[1]); if (staged < G) stage(S[1]); load(S[1]); adv();
+        waitset(0); stageset(0); loadset(0);
+        waitset(1); if (staged < G) stageset(1); loadset(1);
         if (!WCONS) { NTP_WAITW(N_W) }
         while (!done) {             // step g+2 comes from set (g + 2) % SETS: the index is a compile-time constant in the unrolled body
 #pragma unroll
             for (int u = 0; u < SETS; ++u) {
                 NTP_ST(0); ntp_bar(); NTP_STACC(); NTP_ST(1);
                 if (++g == G) { done = true; break; }
-                ntp_wait_set<N_SET>(S[(u + 2) % SETS]); NTP_ST(2);
-                if (staged < G) stage(S[(u + 2) % SETS]);
+                waitset((u + 2) % SETS); NTP_ST(2);
+                if (staged < G) stageset((u + 2) % SETS);
                 NTP_ST(4); if (!WCONS) issue_w(); NTP_ST(5);
-                load(S[(u + 2) % SETS]); adv(); NTP_ST(6);
+                loadset((u + 2) % SETS); NTP_ST(6);
                 if (!WCONS) { NTP_WAITW(N_W) }
                 NTP_ST(7); NTP_STEND();
             }
@@ -586,11 +656,11 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     }
 }
 
-template <typename Cfg, typename AT, typename Epi>
-static int launch_ntp(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st) {
+template <typename Cfg, typename AT, typename Epi, typename Pro = NtpProNone>
+static int launch_ntp(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t st, const Pro& pro = Pro{}) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<Cfg, AT, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<Cfg, AT, Epi, Pro>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::TOTAL);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
@@ -598,8 +668,8 @@ static int launch_ntp(const void* A, long lda, const void* W, long ldw, int M, i
     const int ntiles = ((gx + 7) / 8) * 8 * gy;
     int grid = 256;                                                  // one 8-wave workgroup per CU
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((gemm_ntp_kernel<Cfg, AT, Epi>), dim3(grid), dim3(64 * Cfg::NWAVES), Cfg::TOTAL, st,
-                       (const AT*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi);
+    hipLaunchKernelGGL((gemm_ntp_kernel<Cfg, AT, Epi, Pro>), dim3(grid), dim3(64 * Cfg::NWAVES), Cfg::TOTAL, st,
+                       (const AT*)A, lda, (const bf16*)W, ldw, M, N, K, gx, gy, epi, pro);
     MM_CHECK_LAUNCH();
     return 0;
 }

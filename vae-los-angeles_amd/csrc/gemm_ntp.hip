@@ -30,10 +30,36 @@ static int ntp_epi(const mmvae_gemm_nt_args* a, hipStream_t st) {
     return NTP_SKIP;
 }
 
+// bf16 A through the producers' BatchNorm + ReLU + Dropout prologue (the hidden BN layers' forward: EncoderB's second Linear)
+template <typename Pro>
+static int ntp_pro(const mmvae_gemm_nt_args* a, const Pro& pro, hipStream_t st) {
+    const bool stats = a->stat1 != nullptr || a->stat2 != nullptr;
+    const int bn = a->N % 256 == 0 ? 256 : 128;
+    if (a->c_dtype != MMVAE_BF16 || a->M % 128 || a->N % bn || a->ldc % 64 || ((uintptr_t)a->c & 127)) return NTP_SKIP;
+    if (stats) {
+        EpiStore<bf16, true> e{(bf16*)a->c, a->ldc, a->bias, a->act, 0, nullptr, 0, nullptr, 0, a->stat1, a->stat2};
+        if (bn == 256) return launch_ntp<NtpCfg<4, 4>, bf16, EpiStore<bf16, true>, Pro>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st, pro);
+        return launch_ntp<NtpCfg<4, 2>, bf16, EpiStore<bf16, true>, Pro>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st, pro);
+    }
+    EpiStore<bf16, false> e{(bf16*)a->c, a->ldc, a->bias, a->act, 0, nullptr, 0, nullptr, 0, nullptr, nullptr};
+    if (bn == 256) return launch_ntp<NtpCfg<4, 4>, bf16, EpiStore<bf16, false>, Pro>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st, pro);
+    return launch_ntp<NtpCfg<4, 2>, bf16, EpiStore<bf16, false>, Pro>(a->a, a->lda, a->w, a->ldw, a->M, a->N, a->K, e, st, pro);
+}
+
 // NTP_SKIP: not taken (the caller continues with the tile kernels); anything else is the launch status
 int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st) {
-    if (!g_ntp_on || a->prec != MMVAE_PREC_BF16 || a->prologue != MMVAE_PRO_NONE || a->epilogue != MMVAE_EPI_STORE || a->accumulate) return NTP_SKIP;
+    if (!g_ntp_on || a->prec != MMVAE_PREC_BF16 || a->epilogue != MMVAE_EPI_STORE || a->accumulate) return NTP_SKIP;
     if (a->K <= 64 || a->M < g_ntp_min_m || a->M % 8) return NTP_SKIP;      // M % 8: see the A producers' row groups
+    if (a->prologue == MMVAE_PRO_BN_RELU_DROP) {
+        static const bool off = getenv("MMVAE_NO_NTP_PRO") != nullptr;      // A/B switch
+        if (off || a->a_dtype != MMVAE_BF16 || a->K % 64 || a->K > 512 || a->lda % 8 || ((uintptr_t)a->a & 15) || !a->pro_scale || !a->pro_shift) return NTP_SKIP;
+        if (a->pro_mask) {
+            if (a->ld_pro_mask % 8 || ((uintptr_t)a->pro_mask & 7)) return NTP_SKIP;      // 8 keep bytes per lane and load
+            return ntp_pro(a, NtpProBn<true>{a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep}, st);
+        }
+        return ntp_pro(a, NtpProBn<false>{a->pro_scale, a->pro_shift, nullptr, 0, a->pro_inv_keep}, st);
+    }
+    if (a->prologue != MMVAE_PRO_NONE) return NTP_SKIP;
     if (a->a_dtype == MMVAE_F32) {
         if (a->K < 4 || ((uintptr_t)a->a & 3)) return NTP_SKIP;
         return ntp_epi<float>(a, st);
