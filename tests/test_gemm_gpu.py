@@ -579,3 +579,32 @@ def test_ntp_prologue_matches_tile_kernels(M, N, K, masked, stats):
     assert torch.equal(res[0][0], res[1][0])
     if stats:
         np.testing.assert_allclose(res[1][1].cpu(), res[0][1].cpu(), rtol=2e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K,lda,act", [(1024, 512, 256, 256, ops.ACT_RELU),      # DecoderB's hidden Linear + ReLU (decoders.py:29-30)
+                                           (512, 128, 200, 208, ops.ACT_NONE)])      # K % 64 != 0, row pitch > K
+def test_ntp_plain_bf16_matches_tile_kernels(M, N, K, lda, act):
+    """gemm_ntp.h on a plain bf16 A operand (the producers copy 16-byte chunks into the ring) against the LDS-DMA tile kernel: bit-identical."""
+    g = torch.Generator().manual_seed(M + N + K)
+    Af = torch.zeros(M, lda, dtype=torch.bfloat16, device=DEV)
+    Af[:, :K] = torch.randn(M, K, generator=g).to(DEV)
+    A = Af[:, :K]
+    W = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pl = _prep(W, b, PREC_BF16)
+    res = {}
+    try:
+        _set_tuning(9, 256)
+        for on in (0, 1):
+            _set_tuning(8, on)
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+            ops.gemm_nt(PREC_BF16, A, pl.w, N, K, out, bias=pl.bias, act=act)
+            torch.cuda.synchronize()
+            res[on] = out.clone()
+    finally:
+        _set_tuning(8, 1); _set_tuning(9, 16384)
+    ref = A.double() @ W.to(torch.bfloat16).double().t() + b.double()
+    if act == ops.ACT_RELU:
+        ref = ref.clamp_min(0)
+    assert float((res[1].double() - ref).abs().max()) <= _tol(K, float(ref.abs().max()), True)
+    assert torch.equal(res[0], res[1])

@@ -21,7 +21,9 @@ M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 dev = "cuda"
 lib = L.load()
 lib.mmvae_debug_ntp_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-A = [torch.rand(M, K, device=dev) for _ in range(3)]
+PRO = os.environ.get("PRO") == "1"      # bf16 A through the producers' BatchNorm + ReLU + Dropout prologue (EncoderB's second Linear: N=256 K=512)
+A = [torch.randn(M, K, device=dev).bfloat16() if PRO else torch.rand(M, K, device=dev) for _ in range(3)]
+pro = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3, (torch.rand(M, K, device=dev) > 0.1).to(torch.uint8), 1.0 / 0.9) if PRO else None
 stats = torch.zeros(2, N, dtype=torch.float64, device=dev)
 W = torch.randn(N, K, device=dev) / 30
 pl = ops.PreparedLinear([W], [torch.zeros(N, device=dev)], PREC_BF16, dev)
@@ -32,7 +34,7 @@ buf = (C.c_uint64 * 24)()
 
 def run(reps):
     for i in range(reps):
-        ops.gemm_nt(PREC_BF16, A[i % 3], pl.w, N, K, out, bias=pl.bias, stats=stats)
+        ops.gemm_nt(PREC_BF16, A[i % 3], pl.w, N, K, out, bias=pl.bias, stats=stats, prologue=pro)
     torch.cuda.synchronize()
 
 

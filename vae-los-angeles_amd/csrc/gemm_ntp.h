@@ -32,6 +32,9 @@
 #include "common.h"
 #include "gemm_nt_epi.h"
 
+#ifndef NTP_PRO_WCONS
+#define NTP_PRO_WCONS 1
+#endif
 #ifndef NTP_ABL
 #define NTP_ABL 0              // timing-only ablations (tools/abl_ntp.sh): 1 = W DMA from one fixed K step, 2 = A loads from one fixed K step and row tile,
 #endif                         // 3 = no MFMA, 4 = no epilogue
@@ -194,7 +197,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     // W: the issuing waves' WPW pieces (8 LDS rows each) of the column tile per K step.  LDS row x of the tile's W block holds W row
     // (x & ~63) + EpiCols::wrow(x & 63) (the epilogue's column order), chunk (position ^ (x & 7)): a part per wave (scalar), a
     // compile-time part per piece (scalar multiply) and a lane part in ONE VGPR.  Issued by the consumer waves or by the producers (NtpCfg::WCONS).
-    constexpr bool WCONS = Cfg::WCONS;
+    constexpr bool WCONS = Cfg::WCONS || (Pro::ON && NTP_PRO_WCONS);   // with the operand prologue the producers are busier still (3 400 against 1 160 cycles per K step)
     constexpr int WPW = BN / 8 / (WCONS ? Cfg::NCONS : Cfg::NPA);      // pieces per issuing wave and K step: 4 / 4 (consumers), 8 / 4 (producers)
     constexpr bool PAIRC = EC::G == 8;
     const int widx = WCONS ? wid : wid - Cfg::NCONS;                   // this wave's index among the issuing waves (the other role never issues)
