@@ -106,6 +106,12 @@ typedef struct {
     const uint8_t* epi_mask; int64_t ld_epi_mask; float epi_inv_keep;
     const float* bn_coef; int32_t bn_phase;       /* MMVAE_EPI_BN_BWD: 0 = statistics, 1 = apply (recompute), 2 = statistics + store d */
     double* stat1; double* stat2;                 /* optional [N] f64 accumulators (atomic adds; zero them first) */
+    /* optional, MMVAE_PRO_BN_RELU_DROP with a bf16 A only: the operand AFTER the prologue -- relu(a * scale + shift) * keep / (1 - p),
+       i.e. the previous layer's post-activation (encoders.py:33-34,37-38) -- is also written here ([M][ld_pro_out] bf16, K columns) so
+       that the layer's dW GEMM can read it as a plain operand.  Only the wave-specialised kernel writes it (its producer waves hold the
+       values anyway): MMVAE_ERR_ARG when the problem is not one of its (M >= 16384, M % 128 == 0, N % 128 == 0, N <= 256, K % 64 == 0,
+       K <= 512, bf16 C with whole 128-byte rows). */
+    void* pro_out; int64_t ld_pro_out;
 } mmvae_gemm_nt_args;
 int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
 

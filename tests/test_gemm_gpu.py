@@ -608,3 +608,34 @@ def test_ntp_plain_bf16_matches_tile_kernels(M, N, K, lda, act):
         ref = ref.clamp_min(0)
     assert float((res[1].double() - ref).abs().max()) <= _tol(K, float(ref.abs().max()), True)
     assert torch.equal(res[0], res[1])
+
+
+def test_ntp_prologue_output_is_the_post_activation():
+    """pro_out of mmvae_gemm_nt (wave-specialised kernel only): the operand after BatchNorm-normalise + ReLU + Dropout, bit for bit what
+    the dW GEMM's own operand prologue would form; the GEMM result is unchanged; problems the kernel does not take answer ERR_ARG."""
+    M, N, K = 16384, 256, 512
+    g = torch.Generator().manual_seed(3)
+    Y = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    scale = (torch.rand(K, generator=g) + 0.5).to(DEV); shift = (torch.randn(K, generator=g) * 0.3).to(DEV)
+    mask = (torch.rand(M, K, generator=g) > 0.1).to(torch.uint8).to(DEV)
+    W = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(DEV)
+    pl = _prep(W, torch.zeros(N, device=DEV), PREC_BF16)
+    pro = (scale, shift, mask, 1.0 / 0.9)
+    out0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); out1 = torch.empty_like(out0)
+    H = torch.full((M, K), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert ops.can_keep_pro_out(PREC_BF16, M, N, K, Y, out1)
+    ops.gemm_nt(PREC_BF16, Y, pl.w, N, K, out0, bias=pl.bias, prologue=pro)
+    ops.gemm_nt(PREC_BF16, Y, pl.w, N, K, out1, bias=pl.bias, prologue=pro, pro_out=H)
+    assert torch.equal(out0, out1)
+    ik = torch.tensor(1.0 / 0.9, dtype=torch.float32, device=DEV)
+    want = (torch.relu((Y.double() * (scale * ik).double() + (shift * ik).double()).float()) * mask.float()).bfloat16()     # one fused multiply-add, as the kernel
+    assert torch.equal(H, want)
+    # dW from the kept operand == dW through the operand prologue
+    P = torch.randn(M, 40, generator=g).to(DEV)
+    dw0 = torch.zeros(40, K, device=DEV); db0 = torch.zeros(40, device=DEV); dw1 = torch.zeros_like(dw0); db1 = torch.zeros_like(db0)
+    ops.gemm_tn(PREC_BF16, P, Y, dw0, db0, 40, K, q_prologue=pro)
+    ops.gemm_tn(PREC_BF16, P, H, dw1, db1, 40, K)
+    assert float((dw0 - dw1).abs().max()) <= 1e-5 * float(dw0.abs().max())
+    small = Y[:1024]
+    with pytest.raises(RuntimeError):                         # below the kernel's minimum M: nobody would write pro_out
+        ops.gemm_nt(PREC_BF16, small, pl.w, N, K, out0[:1024], bias=pl.bias, prologue=(scale, shift, mask[:1024], 1.0 / 0.9), pro_out=H[:1024])

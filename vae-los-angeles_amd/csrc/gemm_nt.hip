@@ -494,6 +494,7 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
             const long hsz = (a->prec == MMVAE_PREC_BF16 && !loss_epi) ? 2 : 4;
             if (a->h) s.h = (const char*)a->h + r0 * a->ldh * hsz;
             if (a->pro_mask) s.pro_mask = a->pro_mask + r0 * a->ld_pro_mask;
+            if (a->pro_out) s.pro_out = (char*)a->pro_out + r0 * a->ld_pro_out * 2;
             if (a->epi_mask) s.epi_mask = a->epi_mask + r0 * a->ld_epi_mask;
             const int rc = mmvae_gemm_nt(&s, stream);
             if (rc) return rc;
@@ -502,6 +503,7 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     { const int rc = mm::ntp_dispatch(a, st); if (rc != (1 << 30)) return rc; }
+    if (a->pro_out) return MMVAE_ERR_ARG;              // only the wave-specialised kernel writes the operand after its prologue (mmvae_hip.h)
     if (a->prec == MMVAE_PREC_BF16) return mm::dispatch_src<mm::bf16>(a, st);
     if (a->prec == MMVAE_PREC_F32) return mm::dispatch_src<float>(a, st);
     return MMVAE_ERR_ARG;

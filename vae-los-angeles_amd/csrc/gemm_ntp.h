@@ -136,10 +136,15 @@ __device__ __forceinline__ float ntp_row16_reduce_scatter(const float (&v)[16], 
 // ReLU + Dropout of the previous layer applied on the way into LDS (reference src/models/encoders.py:32-38 in front of the second
 // nn.Linear of EncoderB, :35).  The same arithmetic as SrcBnReluDrop (gemm_src.h): scale and shift pre-multiplied by inv_keep in an LDS
 // table, keep bytes as floats.  MASK = false: eval mode (no dropout).  K % 64 == 0, K <= 512.
-struct NtpProNone { static constexpr bool ON = false, MASK = false; };
+struct NtpProNone {                  // no prologue: the members only keep the (never executed) prologue code well-formed
+    static constexpr bool ON = false, MASK = false;
+    const float* scale = nullptr; const float* shift = nullptr; const uint8_t* mask = nullptr; long ldm = 0; float inv_keep = 1.f;
+    bf16* out = nullptr; long ldo = 0;
+};
 template <bool MASK_> struct NtpProBn {
     static constexpr bool ON = true, MASK = MASK_;
     const float* scale; const float* shift; const uint8_t* mask; long ldm; float inv_keep;
+    bf16* out; long ldo;              // optional: the operand after the prologue, [M][ldo] (written by the column tile 0 workgroups)
 };
 __device__ __forceinline__ void ntp_ld8(f32x2& d, unsigned voff, const void* sbase) {
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
@@ -538,6 +543,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
         unsigned long long stmp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stprev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         int skt = 0, sslot = 0, staged = 0;                          // K step (inside its tile) / ring slot / index of the step that is staged next
+        int s_T = T0, s_row0, s_ct; { int rt_, ct_; tile_rc(T0, rt_, ct_); s_row0 = rt_ * BM; s_ct = ct_; }      // PRO + out: the tile that is being staged
         auto stage = [&](f32x4 (&s)[AI]) __attribute__((always_inline)) {
             unsigned char* sA = smem + sslot * Cfg::A_SLOT;
             const bool rot = krem != 0 && skt == nk - 1;              // wave-uniform
@@ -572,7 +578,11 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
             unsigned char* sA = smem + sslot * Cfg::A_SLOT;
             const float* ap = paux + skt * 64 + 8 * q;
             const f32x4 sc0 = *(const f32x4*)ap, sc1 = *(const f32x4*)(ap + 4), sh0 = *(const f32x4*)(ap + 512), sh1 = *(const f32x4*)(ap + 516);
+            // the tile this step belongs to (the staging position trails the load iterator by SETS steps): its rows for the copy to pro.out
+            const bool keep_out = pro.out != nullptr && s_ct == 0;
+            bf16* const orow = pro.out + (long)s_row0 * pro.ldo + skt * 64 + 8 * q;
             skt = skt + 1 == nk ? 0 : skt + 1;
+            if (skt == 0 && s_T >= 0) { s_T = next_tile(s_T); if (s_T >= 0) { int rt_, ct_; tile_rc(s_T, rt_, ct_); s_row0 = rt_ * BM; s_ct = ct_; } }
             sslot = sslot == Cfg::RA - 1 ? 0 : sslot + 1;
             ++staged;
 #pragma unroll
@@ -592,6 +602,7 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
                     o[e] = (bf16)(v * (float)((mk[e >> 2] >> (8 * (e & 3))) & 0xffu));
                 }
                 *(bf16x8_t*)(sA + r * ROW_BYTES + ((q ^ (r & 7)) << 4)) = o;
+                if (keep_out) *(bf16x8_t*)(orow + (long)r * pro.ldo) = o;      // M % 128 == 0 (dispatch): every row of the tile exists
             }
         };
         // One in-order queue per wave: per iteration g it takes [W(g+2) x WPW, A(g+2+SETS) x AI].  Before barrier g+1 the W of step g+1

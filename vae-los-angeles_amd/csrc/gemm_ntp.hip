@@ -52,12 +52,13 @@ int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st) {
     if (a->K <= 64 || a->M < g_ntp_min_m || a->M % 8) return NTP_SKIP;      // M % 8: see the A producers' row groups
     if (a->prologue == MMVAE_PRO_BN_RELU_DROP) {
         static const bool off = getenv("MMVAE_NO_NTP_PRO") != nullptr;      // A/B switch
+        if (a->pro_out && (a->ld_pro_out % 8 || ((uintptr_t)a->pro_out & 15) || a->ld_pro_out < a->K)) return NTP_SKIP;
         if (off || a->a_dtype != MMVAE_BF16 || a->K % 64 || a->K > 512 || a->lda % 8 || ((uintptr_t)a->a & 15) || !a->pro_scale || !a->pro_shift) return NTP_SKIP;
         if (a->pro_mask) {
             if (a->ld_pro_mask % 8 || ((uintptr_t)a->pro_mask & 7)) return NTP_SKIP;      // 8 keep bytes per lane and load
-            return ntp_pro(a, NtpProBn<true>{a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep}, st);
+            return ntp_pro(a, NtpProBn<true>{a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out}, st);
         }
-        return ntp_pro(a, NtpProBn<false>{a->pro_scale, a->pro_shift, nullptr, 0, a->pro_inv_keep}, st);
+        return ntp_pro(a, NtpProBn<false>{a->pro_scale, a->pro_shift, nullptr, 0, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out}, st);
     }
     if (a->prologue != MMVAE_PRO_NONE) return NTP_SKIP;
     if (a->a_dtype == MMVAE_F32) {

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -42,7 +42,8 @@ class GemmNtArgs(C.Structure):
                 ("bn_scale", vp), ("bn_shift", vp), ("bn_mean", vp), ("bn_rstd", vp),
                 ("epi_mask", vp), ("ld_epi_mask", i64), ("epi_inv_keep", f32),
                 ("bn_coef", vp), ("bn_phase", i32),
-                ("stat1", vp), ("stat2", vp)]
+                ("stat1", vp), ("stat2", vp),
+                ("pro_out", vp), ("ld_pro_out", i64)]
 
 
 class GemmTnArgs(C.Structure):

@@ -178,7 +178,7 @@ class EncoderMLP:
     def widths(self):
         return [l.out_features for l in self.linears]
 
-    def forward(self, prec, x, train, masks, stats_bufs=None):
+    def forward(self, prec, x, train, masks, stats_bufs=None, want_bwd=False):
         """masks: one uint8 (B, width) keep-mask per BN layer (training) or None (eval).
         stats_bufs: optional pre-zeroed float64 (2, N) accumulators, one per BN layer."""
         B, dev = x.shape[0], x.device
@@ -190,9 +190,15 @@ class EncoderMLP:
             N, K = pl.N, pl.K
             y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
             st = BNState(N, dev)
+            # a hidden BN layer on the wave-specialised kernel: its producers also write the operand AFTER the prologue (the previous
+            # layer's post-activation, 2 bytes per element), which lets this layer's dW GEMM run the plain LDS-DMA kernel instead of
+            # redoing the prologue on its Q operand (EncoderB's second Linear: 52 -> 30 us for the dW GEMM)
+            h_act = None
+            if want_bwd and pro is not None and ops.can_keep_pro_out(prec, B, N, K, h, y) and pro[2] is not None and pro[2].stride(0) % 8 == 0:
+                h_act = torch.empty(B, K, dtype=torch.bfloat16, device=dev)
             if train:
                 stats = stats_bufs[len(saved)] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
-                ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd")
+                ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd", pro_out=h_act)
                 ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
                                 bn.momentum if bn.momentum is not None else 0.1)
@@ -202,7 +208,7 @@ class EncoderMLP:
                 ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, tag=f"{self.name}.L{len(saved)}.fwd")
                 ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, st.scale, st.shift, bn.eps, st.mean, st.rstd)
                 new_pro = (st.scale, st.shift, None, 1.0)
-            saved.append((h, pro, y, st, new_pro))
+            saved.append((h, pro, y, st, new_pro) if h_act is None else (h_act, None, y, st, new_pro))      # backward's Q operand: plain when kept
             h, pro = y, new_pro
         heads = torch.empty(B, 2 * self.latent, dtype=torch.float32, device=dev)
         ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
@@ -433,11 +439,11 @@ class VAEGraph:
         # ONE memset for everything this step needs zeroed: forward BatchNorm sums, the loss accumulators, and -- when a backward will
         # follow -- the flat gradient arena with the backward's BatchNorm sums and embedding-table gradient (three fills before)
         st_all = []
+        # decided by the caller (functional.run_graph) BEFORE it enters the autograd.Function, inside which grad mode is always off
+        want_bwd = train and (bool(getattr(self, "_want_bwd", False)) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list())))
         if train:
             specs = [(2 * w, torch.float64) for w in widths_a + widths_b]
             nst = len(specs)
-            # decided by the caller (functional.run_graph) BEFORE it enters the autograd.Function, inside which grad mode is always off
-            want_bwd = bool(getattr(self, "_want_bwd", False)) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list()))
             if want_bwd:
                 specs += [(5, torch.float64), (5, torch.float32)] + self._grad_specs(xa is not None, xb is not None, site is not None)
             packed = zeros_pack(dev, specs)
@@ -448,11 +454,11 @@ class VAEGraph:
         if xa is not None:
             xa = _check_input(xa, "a", self.enc_a.in_dim)
             heads_a, saved["enc_a"] = self.enc_a.forward(prec, xa, train, masks[:len(widths_a)] if train else None,
-                                                         st_all[:len(widths_a)] if train else None)
+                                                         st_all[:len(widths_a)] if train else None, want_bwd=want_bwd)
         if xb is not None:
             xb = _check_input(xb.reshape(xb.shape[0], -1), "b", self.enc_b.in_dim)     # encoders.py:44 view
             heads_b, saved["enc_b"] = self.enc_b.forward(prec, xb, train, masks[len(widths_a):] if train else None,
-                                                         st_all[len(widths_a):] if train else None)
+                                                         st_all[len(widths_a):] if train else None, want_bwd=want_bwd)
         if site is not None:
             if site.dtype != torch.int64:
                 site = site.long()

@@ -195,8 +195,17 @@ class WeightPrep:
 # --------------------------------------------------------------------------------------------
 # GEMMs
 # --------------------------------------------------------------------------------------------
+def can_keep_pro_out(prec, M, N, K, a, out):
+    """Will mmvae_gemm_nt write `pro_out` for this problem?  Mirrors the conditions of the wave-specialised kernel's prologue variant
+    (include/mmvae_hip.h, gemm_ntp.hip): the library answers MMVAE_ERR_ARG when asked for pro_out outside them."""
+    return (prec == PREC_BF16 and a.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and M >= 16384 and M % 128 == 0
+            and N % 128 == 0 and N <= 256 and K % 64 == 0 and 64 < K <= 512 and _ld(a) % 8 == 0 and _ld(out) % 64 == 0
+            and a.data_ptr() % 16 == 0 and out.data_ptr() % 128 == 0 and os.environ.get("MMVAE_NO_NTP") is None
+            and os.environ.get("MMVAE_NO_NTP_PRO") is None and os.environ.get("MMVAE_NO_PRO_OUT") is None)
+
+
 def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
-            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, loss_sum=None, tag=None):
+            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, loss_sum=None, tag=None, pro_out=None):
     """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
     bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD (out=None, stats given:
     statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator.
@@ -214,6 +223,8 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
         g.pro_scale, g.pro_shift, g.pro_mask = sc.data_ptr(), sh.data_ptr(), _p(mask)
         g.ld_pro_mask = _ld(mask) if mask is not None else 0
         g.pro_inv_keep = inv_keep
+        if pro_out is not None:                 # the operand after the prologue (bf16 [M][>= K]); see can_keep_pro_out()
+            g.pro_out, g.ld_pro_out = pro_out.data_ptr(), _ld(pro_out)
     g.w, g.ldw = w_lp.data_ptr(), w_lp.stride(0)
     g.epilogue = epilogue
     if out is not None:
