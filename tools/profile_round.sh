@@ -14,3 +14,4 @@ python3 bench.py --batch 4096 > gpurun_out/r03_prof/bench_b4096.json 2> /dev/nul
 python3 bench.py --batch 32 > gpurun_out/r03_prof/bench_b32.json 2> /dev/null
 MMVAE_FORCE_DP=1 python3 bench.py --cpu-steps 0 > gpurun_out/r03_prof/bench_dp1.json 2> gpurun_out/r03_prof/bench_dp1.err
 python3 tools/bench_infer.py > gpurun_out/r03_prof/infer.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_prof/scaled_stats -- python3 tools/bench_scaled.py > gpurun_out/r03_prof/scaled.log 2>&1
