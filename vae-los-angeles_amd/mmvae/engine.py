@@ -194,11 +194,20 @@ class EncoderMLP:
             # layer's post-activation, 2 bytes per element), which lets this layer's dW GEMM run the plain LDS-DMA kernel instead of
             # redoing the prologue on its Q operand (EncoderB's second Linear: 52 -> 30 us for the dW GEMM)
             h_act = None
-            if want_bwd and pro is not None and ops.can_keep_pro_out(prec, B, N, K, h, y) and pro[2] is not None and pro[2].stride(0) % 8 == 0:
+            if want_bwd and pro is not None and ops.can_keep_pro_out(prec, B, N, K, h, y) and pro[2] is not None \
+                    and pro[2].stride(0) % 8 == 0 and pro[2].data_ptr() % 8 == 0:
                 h_act = torch.empty(B, K, dtype=torch.bfloat16, device=dev)
             if train:
                 stats = stats_bufs[len(saved)] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
-                ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd", pro_out=h_act)
+                try:
+                    ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd", pro_out=h_act)
+                except RuntimeError:
+                    if h_act is None:
+                        raise
+                    # the library did not take the problem on the kernel that writes pro_out (the argument check fails BEFORE anything
+                    # is enqueued): the ordinary call, and the backward redoes the prologue on its operand load
+                    h_act = None
+                    ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd")
                 ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
                                 bn.momentum if bn.momentum is not None else 0.1)

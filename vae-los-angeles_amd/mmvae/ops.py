@@ -200,6 +200,7 @@ def can_keep_pro_out(prec, M, N, K, a, out):
     (include/mmvae_hip.h, gemm_ntp.hip): the library answers MMVAE_ERR_ARG when asked for pro_out outside them."""
     return (prec == PREC_BF16 and a.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and M >= 16384 and M % 128 == 0
             and N % 128 == 0 and N <= 256 and K % 64 == 0 and 64 < K <= 512 and _ld(a) % 8 == 0 and _ld(out) % 64 == 0
+            and M * _ld(a) * 2 < 2 ** 31            # one launch: the row-block path of >= 4 GiB operands is never asked for pro_out
             and a.data_ptr() % 16 == 0 and out.data_ptr() % 128 == 0 and os.environ.get("MMVAE_NO_NTP") is None
             and os.environ.get("MMVAE_NO_NTP_PRO") is None and os.environ.get("MMVAE_NO_PRO_OUT") is None)
 
