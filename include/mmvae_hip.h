@@ -137,6 +137,11 @@ typedef struct {
        p_coef is [3][N] as written by mmvae_bn_bwd_finalize. */
     int32_t p_prologue;
     const void* p_y; int64_t ld_py; const float* p_mean; const float* p_rstd; const float* p_coef;
+    /* p_coef == NULL with MMVAE_PRO_BN_BWD_APPLY: mmvae_bn_bwd_finalize folded into this launch.  The kernel forms the three
+       constants per column from the f64 sums of MMVAE_EPI_BN_BWD (coef = {gamma * rstd, sum_d / M, sum_dx / M}; p_eval_mode != 0:
+       {gamma * rstd, 0, 0}) and ONE workgroup per column tile adds dgamma += sum_dx, dbeta += sum_d.  Only the wide-tile kernels do
+       this (M >= 8192, N >= 128, K >= 256, bf16, slab given): MMVAE_ERR_ARG otherwise -- call mmvae_bn_bwd_finalize and pass p_coef. */
+    const double* p_sum_d; const double* p_sum_dx; const float* p_gamma; float* p_dgamma; float* p_dbeta; int32_t p_eval_mode;
 } mmvae_gemm_tn_args;
 int mmvae_gemm_tn(const mmvae_gemm_tn_args* args, void* stream);
 /* Up to MMVAE_TN_GROUP_MAX small-output problems (same prec; the latent / class-width layers: encoder heads, decoder first
@@ -181,6 +186,12 @@ int mmvae_bn_bwd_finalize(const mmvae_bn_bwd_finalize_args* args, void* stream);
  * MMVAE_EPI_BN_BWD bn_phase 2 (the one-contraction form of BatchNorm backward). */
 int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
                        const float* mean, const float* rstd, const float* coef, void* stream);
+/* mmvae_bn_bwd_finalize + mmvae_bn_bwd_apply in ONE launch: the constants are formed from the f64 sums by every thread for its own
+ * columns, the threads of the first rows add dgamma += sum_dx, dbeta += sum_d.  Same argument limits as mmvae_bn_bwd_apply, and the
+ * column-resident form only (256 % (N / 8) == 0 for bf16, 256 % (N / 4) == 0 for f32: every hidden width of the model); else ERR_ARG. */
+int mmvae_bn_bwd_finalize_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                                const float* mean, const float* rstd, const double* sum_d, const double* sum_dx, const float* gamma,
+                                float* dgamma, float* dbeta, int32_t eval_mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EncoderC (encoders.py:57-61): Embedding + two heads == a per-class table

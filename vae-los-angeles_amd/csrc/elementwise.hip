@@ -119,17 +119,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int N, T* d, l
 // width of the model): a thread keeps ONE column group for all its rows, so the five per-column constants live in registers
 // instead of being re-loaded per vector (40 loads per 16 bytes of d), there is no index division, and U row vectors are in
 // flight per thread (the in-place store would otherwise serialise the loop on one load pair).
-template <typename T, int V, int U>
+// FIN: the constants come from the f64 sums (mmvae_bn_bwd_finalize folded in); the threads of the first row group add dgamma / dbeta
+struct BnBwdFin { const double* sum_d; const double* sum_dx; const float* gamma; float* dgamma; float* dbeta; int eval_mode; };
+template <typename T, int V, int U, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(int M, int N, T* d, long ldd, const T* y, long ldy,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 const float* __restrict__ coef) {
+                                                                 const float* __restrict__ coef, const BnBwdFin fin) {
     const unsigned vpr = N / V, tid = blockIdx.x * 256u + threadIdx.x;
     const unsigned r0 = tid / vpr, c = (tid - r0 * vpr) * V, dr = gridDim.x * 256u / vpr;
     float mu[V], rs[V], c0[V], c1[V], c2[V];
 #pragma unroll
     for (int q = 0; q < V; q += 4) {                                         // V = 4 or 8, N % V == 0
         VLoad<float, 4>::ld(mean + c + q, mu + q); VLoad<float, 4>::ld(rstd + c + q, rs + q);
-        VLoad<float, 4>::ld(coef + c + q, c0 + q); VLoad<float, 4>::ld(coef + N + c + q, c1 + q); VLoad<float, 4>::ld(coef + 2 * N + c + q, c2 + q);
+        if constexpr (!FIN) { VLoad<float, 4>::ld(coef + c + q, c0 + q); VLoad<float, 4>::ld(coef + N + c + q, c1 + q); VLoad<float, 4>::ld(coef + 2 * N + c + q, c2 + q); }
+    }
+    if constexpr (FIN) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const double sd = fin.sum_d[c + e], sdx = fin.sum_dx[c + e];
+            c0[e] = fin.gamma[c + e] * rs[e];
+            c1[e] = fin.eval_mode ? 0.f : (float)(sd / M);
+            c2[e] = fin.eval_mode ? 0.f : (float)(sdx / M);
+            if (r0 == 0) { fin.dbeta[c + e] += (float)sd; fin.dgamma[c + e] += (float)sdx; }      // one thread per column
+        }
     }
     for (unsigned r = r0; r < (unsigned)M; r += U * dr) {
         float dv[U][V], yv[U][V];
@@ -688,7 +700,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 17; }
+extern "C" int mmvae_abi_version(void) { return 18; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;
@@ -728,15 +740,32 @@ extern "C" int mmvae_bn_bwd_apply(int32_t dtype, int32_t M, int32_t N, void* d, 
     if (dtype == MMVAE_BF16) {
         if (N % 8 || ldd % 8 || ldy % 8 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
         if (256 % (N / 8) == 0)
-            hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16, 8, 4>), dim3(grid_for((long)M * N / 8, 256 * 4, 1024)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef);
+            hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16, 8, 4>), dim3(grid_for((long)M * N / 8, 256 * 4, 1024)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef, BnBwdFin{});
         else
             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 8>), dim3(grid_for((long)M * N / 8, 256, 4096)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, coef);
     } else {
         if (N % 4 || ldd % 4 || ldy % 4 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15)) return MMVAE_ERR_ARG;
         if (256 % (N / 4) == 0)
-            hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4, 4>), dim3(grid_for((long)M * N / 4, 256 * 4, 1024)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef);
+            hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4, 4>), dim3(grid_for((long)M * N / 4, 256 * 4, 1024)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef, BnBwdFin{});
         else
             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(grid_for((long)M * N / 4, 256, 4096)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, coef);
+    }
+    MM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmvae_bn_bwd_finalize_apply(int32_t dtype, int32_t M, int32_t N, void* d, int64_t ldd, const void* y, int64_t ldy,
+                                           const float* mean, const float* rstd, const double* sum_d, const double* sum_dx, const float* gamma,
+                                           float* dgamma, float* dbeta, int32_t eval_mode, void* stream) {
+    if (M <= 0 || N <= 0 || !d || !y || !mean || !rstd || !sum_d || !sum_dx || !gamma || !dgamma || !dbeta || (long)M * N >= (1L << 32)) return MMVAE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const BnBwdFin fin{sum_d, sum_dx, gamma, dgamma, dbeta, eval_mode};
+    if (dtype == MMVAE_BF16) {
+        if (N % 8 || ldd % 8 || ldy % 8 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15) || 256 % (N / 8) != 0) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16, 8, 4, true>), dim3(grid_for((long)M * N / 8, 256 * 4, 1024)), dim3(256), 0, st, M, N, (bf16*)d, ldd, (const bf16*)y, ldy, mean, rstd, nullptr, fin);
+    } else {
+        if (N % 4 || ldd % 4 || ldy % 4 || ((uintptr_t)d & 15) || ((uintptr_t)y & 15) || 256 % (N / 4) != 0) return MMVAE_ERR_ARG;
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4, 4, true>), dim3(grid_for((long)M * N / 4, 256 * 4, 1024)), dim3(256), 0, st, M, N, (float*)d, ldd, (const float*)y, ldy, mean, rstd, nullptr, fin);
     }
     MM_CHECK_LAUNCH();
     return 0;

@@ -663,6 +663,7 @@ extern "C" int mmvae_gemm_tn(const mmvae_gemm_tn_args* a, void* stream) {
     if (py_row > row_bytes) row_bytes = py_row;
     if ((long)a->ld_pro_mask > row_bytes) row_bytes = a->ld_pro_mask;
     if ((long)a->M * row_bytes >= mm::g_split_bytes) {
+        if (a->p_prologue != MMVAE_PRO_NONE && !a->p_coef) return MMVAE_ERR_ARG;      // every block would add dgamma / dbeta again: finalise separately
         long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
         if (rows <= 0) return MMVAE_ERR_ARG;
         const long nblk = (a->M + rows - 1) / rows;         // equal blocks (see mmvae_gemm_nt)

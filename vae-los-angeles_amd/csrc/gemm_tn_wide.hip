@@ -28,10 +28,28 @@ namespace mm {
 struct TnwArgs {
     const bf16* p; unsigned ldp; const bf16* py; unsigned ldpy;
     const float* mean; const float* rstd; const float* coef;
+    // coef == nullptr: mmvae_bn_bwd_finalize folded in -- the constants from the f64 sums, dgamma / dbeta by the (zz == 0, tk == 0) workgroups
+    const double* sum_d; const double* sum_dx; const float* gamma; float* dgamma; float* dbeta; int eval_mode;
     const void* q; unsigned ldq;
     int M, N, K, ntk, ntiles, nsplit, rps, linear;
     float* slab; float* db;
 };
+
+// the three BatchNorm-backward constants of column `col` (mmvae_bn_bwd_finalize's coef rows), stored or formed from the sums
+__device__ __forceinline__ void tnw_coef(const TnwArgs& a, int col, float& k0, float& k1, float& k2) {
+    if (a.coef) { k0 = a.coef[col]; k1 = a.coef[a.N + col]; k2 = a.coef[2 * a.N + col]; return; }
+    k0 = a.gamma[col] * a.rstd[col];
+    k1 = a.eval_mode ? 0.f : (float)(a.sum_d[col] / a.M);
+    k2 = a.eval_mode ? 0.f : (float)(a.sum_dx[col] / a.M);
+}
+// dgamma += sum d * xhat, dbeta += sum d: once per column, by the first batch split of the first K tile of every N tile
+__device__ __forceinline__ void tnw_bn_grads(const TnwArgs& a, int n0, int nt, int zz, int tk, int tid, int nthreads) {
+    if (a.coef || zz != 0 || tk != 0) return;
+    for (int c = tid; c < nt; c += nthreads) {
+        const int col = n0 + c;
+        if (col < a.N) { a.dbeta[col] += (float)a.sum_d[col]; a.dgamma[col] += (float)a.sum_dx[col]; }
+    }
+}
 
 template <int WN_, int PA_, int WK_, int QB_> struct TnwCfg {
     static constexpr int WN = WN_, PA = PA_, WK = WK_, QB = QB_;
@@ -100,10 +118,12 @@ void gemm_tnw_kernel(const TnwArgs a)
         for (int c = tid; c < C::NT; c += C::THREADS) {
             const int col = n0 + c;
             const bool ok = col < N;
-            const float c0 = ok ? a.coef[col] : 0.f;
+            float c0 = 0.f, k1 = 0.f, k2 = 0.f;
+            if (ok) tnw_coef(a, col, c0, k1, k2);
             aux[c] = ok ? a.mean[col] : 0.f; aux[C::NT + c] = c0;
-            aux[2 * C::NT + c] = ok ? c0 * a.coef[2 * N + col] * a.rstd[col] : 0.f; aux[3 * C::NT + c] = ok ? c0 * a.coef[N + col] : 0.f;
+            aux[2 * C::NT + c] = ok ? c0 * k2 * a.rstd[col] : 0.f; aux[3 * C::NT + c] = ok ? c0 * k1 : 0.f;
         }
+        tnw_bn_grads(a, n0, C::NT, zz, tk, tid, C::THREADS);
         __syncthreads();
     }
 
@@ -309,10 +329,12 @@ void gemm_tnw_dma_kernel(const TnwArgs a)
         for (int i = 0; i < C::PA; ++i) {
             const int col = n0 + (wn * C::PA + i) * 16 + li;
             const bool ok = col < N;
-            const float k0_ = ok ? a.coef[col] : 0.f;
+            float k0_ = 0.f, k1_ = 0.f, k2_ = 0.f;
+            if (ok) tnw_coef(a, col, k0_, k1_, k2_);
             cm[i] = ok ? a.mean[col] : 0.f; c0[i] = k0_;
-            c2[i] = ok ? k0_ * a.coef[2 * N + col] * a.rstd[col] : 0.f; c1[i] = ok ? k0_ * a.coef[N + col] : 0.f;
+            c2[i] = ok ? k0_ * k2_ * a.rstd[col] : 0.f; c1[i] = ok ? k0_ * k1_ : 0.f;
         }
+        tnw_bn_grads(a, n0, C::NT, zz, tk, tid, C::THREADS);
     }
 
     // DMA source offsets (elements, relative to the first row of a step) of this lane's chunk in each piece this wave issues
@@ -539,7 +561,9 @@ int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out)
     const int pmode = a->p_prologue == MMVAE_PRO_BN_BWD_APPLY ? 1 : 0;
     if (a->p_prologue != MMVAE_PRO_NONE && !pmode) return NA;
     if (a->ldp % 8 || ((uintptr_t)a->p & 15)) return NA;
-    if (pmode && (!a->p_y || !a->p_mean || !a->p_rstd || !a->p_coef || a->ld_py % 8 || ((uintptr_t)a->p_y & 15) || a->N % 8)) return NA;
+    const bool fin = pmode && !a->p_coef;                 // mmvae_bn_bwd_finalize folded in
+    if (pmode && (!a->p_y || !a->p_mean || !a->p_rstd || a->ld_py % 8 || ((uintptr_t)a->p_y & 15) || a->N % 8)) return NA;
+    if (fin && (!a->p_sum_d || !a->p_sum_dx || !a->p_gamma || !a->p_dgamma || !a->p_dbeta)) return NA;
     int qkind;                                             // 0 bf16, 4 / 2: fp32 in vectors of 4 / 2
     if (a->q_dtype == MMVAE_BF16) { if (a->ldq % 8 || ((uintptr_t)a->q & 15)) return NA; qkind = 0; }
     else if (a->ldq % 4 == 0 && a->K % 4 == 0 && ((uintptr_t)a->q & 15) == 0) qkind = 4;
@@ -576,6 +600,7 @@ int launch_tn_wide(const mmvae_gemm_tn_args* a, hipStream_t st, int* nsplit_out)
     w.nsplit = nsplit; w.rps = rps; w.linear = nsplit < 8 ? 1 : 0;
     w.p = (const bf16*)a->p; w.ldp = (unsigned)a->ldp; w.py = (const bf16*)a->p_y; w.ldpy = (unsigned)a->ld_py;
     w.mean = a->p_mean; w.rstd = a->p_rstd; w.coef = a->p_coef;
+    w.sum_d = a->p_sum_d; w.sum_dx = a->p_sum_dx; w.gamma = a->p_gamma; w.dgamma = a->p_dgamma; w.dbeta = a->p_dbeta; w.eval_mode = a->p_eval_mode;
     w.q = a->q; w.ldq = (unsigned)a->ldq; w.M = a->M; w.N = a->N; w.K = a->K; w.slab = a->slab; w.db = a->db;
     *nsplit_out = nsplit;
     if (qkind == 0) return tnw_dma_launch<CfgA, 0, bf16, 3>(w, st);

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -54,7 +54,8 @@ class GemmTnArgs(C.Structure):
                 ("pro_scale", vp), ("pro_shift", vp), ("pro_mask", vp), ("ld_pro_mask", i64), ("pro_inv_keep", f32),
                 ("dw", vp), ("lddw", i64), ("db", vp),
                 ("nsplit", i32), ("slab", vp), ("slab_elems", i64),
-                ("p_prologue", i32), ("p_y", vp), ("ld_py", i64), ("p_mean", vp), ("p_rstd", vp), ("p_coef", vp)]
+                ("p_prologue", i32), ("p_y", vp), ("ld_py", i64), ("p_mean", vp), ("p_rstd", vp), ("p_coef", vp),
+                ("p_sum_d", vp), ("p_sum_dx", vp), ("p_gamma", vp), ("p_dgamma", vp), ("p_dbeta", vp), ("p_eval_mode", i32)]
 
 
 class ScaleItem(C.Structure):
@@ -122,6 +123,7 @@ _SIGNATURES = {
     "mmvae_bn_eval_coeffs": [i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp],
     "mmvae_bn_bwd_finalize": [C.POINTER(BnBwdFinalizeArgs), vp],
     "mmvae_bn_bwd_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp],
+    "mmvae_bn_bwd_finalize_apply": [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "mmvae_embed_table_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "mmvae_embed_table_bwd": [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
     "mmvae_fuse_reparam_fwd": [C.POINTER(FuseFwdArgs), vp],

@@ -22,6 +22,7 @@ _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
 _FUSE_BN_APPLY = os.environ.get("MMVAE_FUSE_BN_APPLY", "1") == "1"       # A/B switch: BN-backward correction of first layers inside the dW GEMM
 _GROUP_TINY_DW = os.environ.get("MMVAE_GROUP_TINY_DW", "1") == "1"       # A/B switch: small-output dW GEMMs as grouped launches
+_FOLD_BN_FINALIZE = os.environ.get("MMVAE_NO_FOLD_BN_FINALIZE") is None      # A/B switch: mmvae_bn_bwd_finalize inside its consumers
 _TINY_DW_MAX = 16384                                                       # N*K at or below which a dW GEMM counts as small-output
 
 
@@ -249,15 +250,35 @@ class EncoderMLP:
             coef = torch.empty(3, N, dtype=torch.float32, device=dev)
             d = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)                  # d := dL/dy_i
             ops.gemm_nt(prec, src, src_wt, src_n, src_k, d, epilogue=EPI_BN_BWD, h=y, bn=bnargs, bn_phase=2, stats=stats, tag=f"{self.name}.L{i}.dX")
-            ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
+            # The finalisation of the backward sums (dgamma, dbeta, the three constants per column) rides in the launch that consumes
+            # them -- the first layer's dW GEMM or the in-place correction pass -- instead of a 5 us launch of its own (round 3); the
+            # library answers ERR_ARG where its kernels cannot do that (small batches, unusual widths): then the separate launch.
+            fin = (stats, bn.weight, grads[bn.weight], grads[bn.bias], not train)
             # (not for very wide inputs -- the scaled omics widths: the dW GEMM then has hundreds of K tiles and every one of them
             # would redo the correction of its P rows; one pass over d is cheaper)
             if i == 0 and _FUSE_BN_APPLY and K <= 4096:
                 # first layer: only the dW GEMM consumes dL/dy -> the correction rides on its operand load, no pass over d
+                if _FOLD_BN_FINALIZE and prec == PREC_BF16 and B >= 8192 and N >= 128 and K >= 256:
+                    try:
+                        tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
+                           p_prologue=(y, st.mean, st.rstd, None, fin), tag=f"{self.name}.L{i}.dW")
+                        continue
+                    except RuntimeError:
+                        pass                                   # refused before anything was enqueued
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
                 tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in,
                    p_prologue=(y, st.mean, st.rstd, coef), tag=f"{self.name}.L{i}.dW")
                 continue
-            ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
+            done = False
+            if _FOLD_BN_FINALIZE:
+                try:
+                    ops.bn_bwd_finalize_apply(d, y, B, N, st.mean, st.rstd, *fin)
+                    done = True
+                except RuntimeError:
+                    pass
+            if not done:
+                ops.bn_bwd_finalize(B, N, stats, bn.weight, st.rstd, grads[bn.weight], grads[bn.bias], coef, eval_mode=not train)
+                ops.bn_bwd_apply(d, y, N, st.mean, st.rstd, coef)
             tn(prec, d, h_in, grads[lin.weight], grads[lin.bias], N, K, q_prologue=pro_in, tag=f"{self.name}.L{i}.dW")
             src, src_wt, src_n, src_k = d, pl.wt, K, N
 

@@ -268,11 +268,19 @@ def _tn_args(prec, p, q, dw, db, N, K, q_prologue, p_prologue, nsplit, slab):
         g.ld_pro_mask = _ld(mask) if mask is not None else 0
         g.pro_inv_keep = inv_keep
     if p_prologue is not None:
-        py, mean, rstd, coef = p_prologue
+        py, mean, rstd, coef = p_prologue[:4]
         _mat(py, "p_y")
-        assert py.dtype == p.dtype and coef.shape[0] == 3 and coef.shape[1] == N and coef.is_contiguous()
         g.p_prologue = PRO_BN_BWD_APPLY
-        g.p_y, g.ld_py, g.p_mean, g.p_rstd, g.p_coef = py.data_ptr(), _ld(py), mean.data_ptr(), rstd.data_ptr(), coef.data_ptr()
+        g.p_y, g.ld_py, g.p_mean, g.p_rstd = py.data_ptr(), _ld(py), mean.data_ptr(), rstd.data_ptr()
+        if coef is not None:
+            assert py.dtype == p.dtype and coef.shape[0] == 3 and coef.shape[1] == N and coef.is_contiguous()
+            g.p_coef = coef.data_ptr()
+        else:
+            # mmvae_bn_bwd_finalize folded into the GEMM: p_prologue = (y, mean, rstd, None, (stats f64 [2][N], gamma, dgamma, dbeta, eval_mode))
+            stats, gamma, dgamma, dbeta, eval_mode = p_prologue[4]
+            assert py.dtype == p.dtype and stats.dtype == torch.float64 and stats.shape[0] == 2 and stats.stride(1) == 1
+            g.p_sum_d, g.p_sum_dx, g.p_gamma = stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr()
+            g.p_dgamma, g.p_dbeta, g.p_eval_mode = dgamma.data_ptr(), dbeta.data_ptr(), int(eval_mode)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     g.dw, g.lddw, g.db = dw.data_ptr(), K, _p(db)
     g.nsplit = nsplit
@@ -345,6 +353,14 @@ def bn_bwd_finalize(M, N, stats, gamma, rstd, dgamma, dbeta, coef, eval_mode=Fal
     a = L.BnBwdFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
                             gamma.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), int(eval_mode))
     L.check(L.load().mmvae_bn_bwd_finalize(C.byref(a), _stream()), "mmvae_bn_bwd_finalize")
+
+
+def bn_bwd_finalize_apply(d, y, M, N, mean, rstd, stats, gamma, dgamma, dbeta, eval_mode=False):
+    """mmvae_bn_bwd_finalize + mmvae_bn_bwd_apply in one launch (the hidden widths of the model; raises for others)."""
+    with probe_span(f"bn_bwd_apply.N{N}", 3 * d.shape[0] * N * d.element_size()):
+        L.check(L.load().mmvae_bn_bwd_finalize_apply(_dt(d), M, N, d.data_ptr(), _ld(d), y.data_ptr(), _ld(y), mean.data_ptr(), rstd.data_ptr(),
+                                                     stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                     int(eval_mode), _stream()), "mmvae_bn_bwd_finalize_apply")
 
 
 def bn_bwd_apply(d, y, N, mean, rstd, coef):
