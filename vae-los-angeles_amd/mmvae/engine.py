@@ -419,11 +419,34 @@ class VAEGraph:
         # reconstruction losses inside their last GEMM instead of returning the reconstruction (see DecoderMLP.forward).
         self.fused_recon = None
 
+    def _late_decoder_params(self):
+        """Decoder tensors whose dW GEMM is small-output (latent / class widths: the decoders' first layers, DecoderC): they are
+        computed by the grouped launch at the END of backward, so under data parallelism they travel with the encoder half of the
+        gradient arena instead of forcing an early flush of that launch."""
+        out = []
+        for d in self.decoders:
+            for l in d.linears:
+                if _GROUP_TINY_DW and l.weight.numel() <= _TINY_DW_MAX:
+                    out += [l.weight, l.bias]
+        return out
+
     def param_list(self):
+        """Order of the flat gradient arena: encoders, the decoders' small-output tensors, then the large decoder tensors -- the tail
+        (from early_cut() on) is final when the decoders' backward is done and is all-reduced under the encoder backward."""
         out = []
         for b in self.blocks:
-            out += b.params()
+            if b not in self.decoders:
+                out += b.params()
+        late = self._late_decoder_params()
+        out += late
+        ids = {id(p) for p in late}
+        for d in self.decoders:
+            out += [p for p in d.params() if id(p) not in ids]
         return out
+
+    def early_cut(self):
+        """Index into the arena where the early all-reduce bucket starts."""
+        return sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()) + sum(p.numel() for p in self._late_decoder_params())
 
     def _ensure_prepared(self, prec, device):
         key = (prec, str(device)) + tuple(p.data_ptr() for p in self.param_list())
@@ -615,11 +638,11 @@ class VAEGraph:
             dzs.append(dz)
         if not dzs:
             dzs.append(torch.zeros(B, Ld, dtype=torch.float32, device=dev))
-        if self.grad_sync is not None:                    # data parallel: the decoder gradients must be final for the early all-reduce bucket;
-            flush_tiny("tiny_dW.decoders")                # otherwise they wait for the encoder heads and share ONE grouped launch + reduce
         if self.grad_sync is not None:
-            # decoder gradients (tail of the arena) are final: start reducing them under the encoder backward
-            self.grad_sync.early(flat, sum(p.numel() for b in self.blocks if b not in self.decoders for p in b.params()))
+            # the large decoder gradients (tail of the arena) are final: start reducing them under the encoder backward.  The decoders'
+            # small-output tensors sit in front of the cut: their grouped dW launch stays ONE launch at the end of backward, as on one GPU
+            # (round 3; before, data parallelism flushed that launch here: an extra grouped GEMM + reduce per step).
+            self.grad_sync.early(flat, self.early_cut())
         n_mod = saved["n_mod"]
         d_heads = torch.empty(B, 2 * Ld, dtype=torch.float32, device=dev)
         d_table = extra[-1][:n_tab].view(L_.TABLE_COPIES, -1, 2 * Ld) if site is not None else None
