@@ -112,6 +112,12 @@ typedef struct {
        values anyway): MMVAE_ERR_ARG when the problem is not one of its (M >= 16384, M % 128 == 0, N % 128 == 0, N <= 256, K % 64 == 0,
        K <= 512, bf16 C with whole 128-byte rows). */
     void* pro_out; int64_t ld_pro_out;
+    /* optional, MMVAE_PRO_BN_RELU_DROP: `const mmvae_bn_finalize_args*` (host memory, read during the call).  mmvae_bn_finalize of the
+       layer that produced A is folded into this launch: every workgroup forms scale / shift of A's columns from the f64 column sums
+       (pro_scale / pro_shift are then ignored), and ONE workgroup writes what mmvae_bn_finalize writes -- mean, rstd, scale, shift, the
+       running statistics and num_batches_tracked -- for the backward pass.  fin->N must equal K.  Not for operands of 4 GiB or more
+       (MMVAE_ERR_ARG: the row blocks would each update the running statistics). */
+    const void* pro_finalize;
 } mmvae_gemm_nt_args;
 int mmvae_gemm_nt(const mmvae_gemm_nt_args* args, void* stream);
 

@@ -700,7 +700,7 @@ static inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 using namespace mm;
 
-extern "C" int mmvae_abi_version(void) { return 18; }
+extern "C" int mmvae_abi_version(void) { return 19; }
 
 extern "C" int mmvae_prep_weights(const mmvae_prep_item* items_dev, int32_t n_items, void* stream) {
     if (!items_dev || n_items <= 0) return MMVAE_ERR_ARG;

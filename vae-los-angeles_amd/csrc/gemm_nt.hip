@@ -414,15 +414,31 @@ static int dispatch_epi(const mmvae_gemm_nt_args* a, const Src& src, hipStream_t
     return MMVAE_ERR_ARG;
 }
 
+// the folded mmvae_bn_finalize of the operand's producer (mmvae_gemm_nt_args::pro_finalize), or "off"
+BnFin bn_fin_of(const mmvae_gemm_nt_args* a) {
+    BnFin f;
+    if (!a->pro_finalize) return f;
+    const mmvae_bn_finalize_args* b = (const mmvae_bn_finalize_args*)a->pro_finalize;
+    f.sum = b->sum; f.sumsq = b->sumsq; f.gamma = b->gamma; f.beta = b->beta; f.eps = b->eps; f.momentum = b->momentum;
+    f.running_mean = b->running_mean; f.running_var = b->running_var; f.nbt = (long long*)b->num_batches_tracked;
+    f.mean = b->mean; f.rstd = b->rstd; f.scale = b->scale; f.shift = b->shift; f.M = b->M;
+    return f;
+}
+static bool bn_fin_ok(const mmvae_gemm_nt_args* a) {
+    if (!a->pro_finalize) return true;
+    const mmvae_bn_finalize_args* b = (const mmvae_bn_finalize_args*)a->pro_finalize;
+    return a->prologue == MMVAE_PRO_BN_RELU_DROP && b->N == a->K && b->M >= 2 && b->sum && b->sumsq && b->gamma && b->beta && b->mean && b->rstd && b->scale && b->shift;
+}
+
 template <typename CT>
 static int dispatch_src(const mmvae_gemm_nt_args* a, hipStream_t st) {
     constexpr int EPC = Mma<CT>::EPC;
     if (a->prologue == MMVAE_PRO_BN_RELU_DROP) {
         // A must be the activation type of this precision mode, 16-byte aligned rows
         if ((a->a_dtype == MMVAE_BF16) != (sizeof(CT) == 2)) return MMVAE_ERR_DTYPE;
-        if (a->K > 512 || a->lda % EPC || ((uintptr_t)a->a & 15) || !a->pro_scale || !a->pro_shift) return MMVAE_ERR_ARG;
+        if (a->K > 512 || a->lda % EPC || ((uintptr_t)a->a & 15) || (!a->pro_finalize && (!a->pro_scale || !a->pro_shift))) return MMVAE_ERR_ARG;
         if (a->pro_mask && (a->ld_pro_mask % 4 || ((uintptr_t)a->pro_mask & 3))) return MMVAE_ERR_ARG;
-        SrcBnReluDrop<CT> s{(const CT*)a->a, a->lda, a->M, a->K, a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep};
+        SrcBnReluDrop<CT> s{(const CT*)a->a, a->lda, a->M, a->K, a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep, bn_fin_of(a)};
         return dispatch_epi<CT>(a, s, st);
     }
     if (a->a_dtype == MMVAE_BF16) {
@@ -476,7 +492,9 @@ extern "C" int mmvae_gemm_nt(const mmvae_gemm_nt_args* a, void* stream) {
     if (((long)a->N + 256) * a->ldw * 4 >= lim) return MMVAE_ERR_ARG;
     const long a_row = (long)a->lda * (a->a_dtype == MMVAE_BF16 ? 2 : 4);
     long row_bytes = a_row > (long)a->ld_pro_mask ? a_row : (long)a->ld_pro_mask;
+    if (!mm::bn_fin_ok(a)) return MMVAE_ERR_ARG;
     if ((long)a->M * row_bytes >= mm::g_split_bytes) {
+        if (a->pro_finalize) return MMVAE_ERR_ARG;           // every row block would update the running statistics
         long rows = mm::g_block_bytes / row_bytes;          // block < split threshold: the recursion below ends after one level
         if (rows <= 0) return MMVAE_ERR_ARG;
         const long nblk = (a->M + rows - 1) / rows;         // equal blocks (65 536 rows -> 4 x 16 384, not 3 x 19 712 + 6 400: a short

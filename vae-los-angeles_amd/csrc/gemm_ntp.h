@@ -31,6 +31,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_nt_epi.h"
+#include "gemm_src.h"
 
 #ifndef NTP_PRO_WCONS
 #define NTP_PRO_WCONS 1
@@ -140,11 +141,13 @@ struct NtpProNone {                  // no prologue: the members only keep the (
     static constexpr bool ON = false, MASK = false;
     const float* scale = nullptr; const float* shift = nullptr; const uint8_t* mask = nullptr; long ldm = 0; float inv_keep = 1.f;
     bf16* out = nullptr; long ldo = 0;
+    BnFin fin = BnFin{};
 };
 template <bool MASK_> struct NtpProBn {
     static constexpr bool ON = true, MASK = MASK_;
     const float* scale; const float* shift; const uint8_t* mask; long ldm; float inv_keep;
     bf16* out; long ldo;              // optional: the operand after the prologue, [M][ldo] (written by the column tile 0 workgroups)
+    BnFin fin;                        // optional (sum != nullptr): mmvae_bn_finalize of the operand's producer folded in (gemm_src.h)
 };
 __device__ __forceinline__ void ntp_ld8(f32x2& d, unsigned voff, const void* sbase) {
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
@@ -196,7 +199,11 @@ void gemm_ntp_kernel(const AT* __restrict__ A, long lda, const bf16* __restrict_
     for (int T = T0; T >= 0; T = next_tile(T)) G += nk;
 
     if constexpr (PRO) {
-        for (int i = tid; i < K; i += 64 * Cfg::NWAVES) { paux[i] = pro.scale[i] * pro.inv_keep; paux[512 + i] = pro.shift[i] * pro.inv_keep; }
+        if (pro.fin.sum) {
+            for (int i = tid; i < K; i += 64 * Cfg::NWAVES) { float sc, sh; pro.fin.column(i, blockIdx.x == 0, sc, sh); paux[i] = sc * pro.inv_keep; paux[512 + i] = sh * pro.inv_keep; }
+        } else {
+            for (int i = tid; i < K; i += 64 * Cfg::NWAVES) { paux[i] = pro.scale[i] * pro.inv_keep; paux[512 + i] = pro.shift[i] * pro.inv_keep; }
+        }
         __syncthreads();                                  // the producers stage their first K steps in front of the loop's first barrier
     }
     // W: the issuing waves' WPW pieces (8 LDS rows each) of the column tile per K step.  LDS row x of the tile's W block holds W row

@@ -5,6 +5,7 @@
 
 namespace mm {
 
+BnFin bn_fin_of(const mmvae_gemm_nt_args* a);               // gemm_nt.hip
 static int g_ntp_on = getenv("MMVAE_NO_NTP") ? 0 : 1;        // mmvae_set_tuning key 8 (tests flip it to compare with the tile kernels)
 static int g_ntp_min_m = 16384;                               // key 9: below this a persistent 256-workgroup grid has < 1 tile per CU
 void ntp_set(int key, int value) { if (key == 8) g_ntp_on = value; else g_ntp_min_m = value; }
@@ -53,12 +54,12 @@ int ntp_dispatch(const mmvae_gemm_nt_args* a, hipStream_t st) {
     if (a->prologue == MMVAE_PRO_BN_RELU_DROP) {
         static const bool off = getenv("MMVAE_NO_NTP_PRO") != nullptr;      // A/B switch
         if (a->pro_out && (a->ld_pro_out % 8 || ((uintptr_t)a->pro_out & 15) || a->ld_pro_out < a->K)) return NTP_SKIP;
-        if (off || a->a_dtype != MMVAE_BF16 || a->K % 64 || a->K > 512 || a->lda % 8 || ((uintptr_t)a->a & 15) || !a->pro_scale || !a->pro_shift) return NTP_SKIP;
+        if (off || a->a_dtype != MMVAE_BF16 || a->K % 64 || a->K > 512 || a->lda % 8 || ((uintptr_t)a->a & 15) || (!a->pro_finalize && (!a->pro_scale || !a->pro_shift))) return NTP_SKIP;
         if (a->pro_mask) {
             if (a->ld_pro_mask % 8 || ((uintptr_t)a->pro_mask & 7)) return NTP_SKIP;      // 8 keep bytes per lane and load
-            return ntp_pro(a, NtpProBn<true>{a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out}, st);
+            return ntp_pro(a, NtpProBn<true>{a->pro_scale, a->pro_shift, a->pro_mask, a->ld_pro_mask, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out, bn_fin_of(a)}, st);
         }
-        return ntp_pro(a, NtpProBn<false>{a->pro_scale, a->pro_shift, nullptr, 0, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out}, st);
+        return ntp_pro(a, NtpProBn<false>{a->pro_scale, a->pro_shift, nullptr, 0, a->pro_inv_keep, (bf16*)a->pro_out, a->ld_pro_out, bn_fin_of(a)}, st);
     }
     if (a->prologue != MMVAE_PRO_NONE) return NTP_SKIP;
     if (a->a_dtype == MMVAE_F32) {

@@ -89,6 +89,33 @@ struct SrcPlain {
 // A = dropout(relu(y * scale + shift)) where y is the previous layer's pre-BatchNorm output,
 // scale = gamma * rstd, shift = beta - mean * scale (per column, staged in LDS), and the keep
 // mask is a uint8 [M][ldm] tensor (1 = kept) or NULL (eval / p = 0).
+// mmvae_bn_finalize folded into the consumer of its result (round 3): the BatchNorm constants of the operand's columns straight from
+// the f64 column sums of the producing GEMM.  sum == nullptr: off.  The arithmetic is bn_finalize_kernel's (elementwise.hip), so the
+// tables are bit-identical to the two-launch form; workgroup 0 also writes that kernel's outputs (backward reads them, later launches).
+struct BnFin {
+    const double* sum = nullptr; const double* sumsq = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    float eps = 0.f, momentum = 0.f;
+    float* running_mean = nullptr; float* running_var = nullptr; long long* nbt = nullptr;
+    float* mean = nullptr; float* rstd = nullptr; float* scale = nullptr; float* shift = nullptr; int M = 0;
+    // scale / shift of column i (as mmvae_bn_finalize rounds them); first_wg: this workgroup stores the outputs
+    __device__ __forceinline__ void column(int i, bool first_wg, float& sc, float& sh) const {
+        const double mean_ = sum[i] / M;
+        double var = sumsq[i] / M - mean_ * mean_;
+        if (var < 0.0) var = 0.0;
+        const float rs = (float)(1.0 / sqrt(var + (double)eps));
+        sc = gamma[i] * rs; sh = beta[i] - (float)mean_ * sc;
+        if (first_wg) {
+            mean[i] = (float)mean_; rstd[i] = rs; scale[i] = sc; shift[i] = sh;
+            if (running_mean) {
+                running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * (float)mean_;
+                const double unbiased = var * ((double)M / (double)(M - 1));
+                running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unbiased;
+            }
+            if (i == 0 && nbt) *nbt += 1;
+        }
+    }
+};
+
 template <typename CT>
 struct SrcBnReluDrop {
     static constexpr int EPC = Mma<CT>::EPC;
@@ -97,11 +124,17 @@ struct SrcBnReluDrop {
     const CT* y; long ldy; int M, K;
     const float* scale; const float* shift;
     const uint8_t* mask; long ldm; float inv_keep;
+    BnFin fin = BnFin{};
     struct Raw { RawVec<CT, EPC> y; uint32_t m[EPC / 4]; };
     __device__ __forceinline__ void init(float* aux, int tid, int) const {
         // relu(y sc + sh) * inv_keep == relu(y (sc inv_keep) + sh inv_keep) for inv_keep > 0: folded here once per workgroup.
         // The keep bytes (0 or 1, mmvae_noise) then multiply as floats (v_cvt_f32_ubyteN): 4 VALU per element instead of 7 in
         // the registers->LDS stage, which is VALU-sensitive (see the BatchNorm-backward source below).
+        if (fin.sum) {
+            const bool first_wg = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+            for (int i = tid; i < K; i += NTHREADS) { float sc, sh; fin.column(i, first_wg, sc, sh); aux[i] = sc * inv_keep; aux[512 + i] = sh * inv_keep; }
+            return;
+        }
         for (int i = tid; i < K; i += NTHREADS) { aux[i] = scale[i] * inv_keep; aux[512 + i] = shift[i] * inv_keep; }
     }
     __device__ __forceinline__ void fetch(Raw& r, int row, int k) const {        // K % EPC == 0 (hidden widths)

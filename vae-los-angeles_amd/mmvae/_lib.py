@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")     # override: experimental builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 F32, BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -43,7 +43,7 @@ class GemmNtArgs(C.Structure):
                 ("epi_mask", vp), ("ld_epi_mask", i64), ("epi_inv_keep", f32),
                 ("bn_coef", vp), ("bn_phase", i32),
                 ("stat1", vp), ("stat2", vp),
-                ("pro_out", vp), ("ld_pro_out", i64)]
+                ("pro_out", vp), ("ld_pro_out", i64), ("pro_finalize", vp)]
 
 
 class GemmTnArgs(C.Structure):

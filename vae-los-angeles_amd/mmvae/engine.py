@@ -22,7 +22,7 @@ _PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 _default_precision = _PRECISIONS[os.environ.get("MMVAE_PRECISION", "bf16").lower()]
 _FUSE_BN_APPLY = os.environ.get("MMVAE_FUSE_BN_APPLY", "1") == "1"       # A/B switch: BN-backward correction of first layers inside the dW GEMM
 _GROUP_TINY_DW = os.environ.get("MMVAE_GROUP_TINY_DW", "1") == "1"       # A/B switch: small-output dW GEMMs as grouped launches
-_FOLD_BN_FINALIZE = os.environ.get("MMVAE_NO_FOLD_BN_FINALIZE") is None      # A/B switch: mmvae_bn_bwd_finalize inside its consumers
+_FOLD_BN_FINALIZE = os.environ.get("MMVAE_NO_FOLD_BN_FINALIZE") is None      # A/B switch: mmvae_bn_finalize / mmvae_bn_bwd_finalize inside their consumers
 _TINY_DW_MAX = 16384                                                       # N*K at or below which a dW GEMM counts as small-output
 
 
@@ -186,32 +186,50 @@ class EncoderMLP:
         adt = act_dtype(prec)
         saved = []
         h, pro = x, None
-        nt = (B + TILE - 1) // TILE
+        fin = None            # the BatchNorm finalisation of the layer that produced h, still owed: it rides in the GEMM that consumes h
+
+        def consume(N, K, out, bias, w, tag, stats=None, pro_out=None):
+            """GEMM on (h, pro) that also finalises h's BatchNorm statistics when the library can fold that in; else the launch of its own."""
+            nonlocal fin
+            if fin is not None and _FOLD_BN_FINALIZE:
+                try:
+                    ops.gemm_nt(prec, h, w, N, K, out, bias=bias, prologue=pro, stats=stats, tag=tag, pro_out=pro_out, pro_finalize=fin)
+                    fin = None
+                    return pro_out
+                except RuntimeError:
+                    pass                                   # refused before anything was enqueued (argument check)
+            if fin is not None:
+                ops.bn_finalize(0, 0, None, None, None, None, None, None, None, None, None, None, args=fin)
+                fin = None
+            try:
+                ops.gemm_nt(prec, h, w, N, K, out, bias=bias, prologue=pro, stats=stats, tag=tag, pro_out=pro_out)
+                return pro_out
+            except RuntimeError:
+                if pro_out is None:
+                    raise
+                # the library did not take the problem on the kernel that writes pro_out: the ordinary call, and the backward redoes
+                # the prologue on its operand load
+                ops.gemm_nt(prec, h, w, N, K, out, bias=bias, prologue=pro, stats=stats, tag=tag)
+                return None
+
         for lin, bn, pl in zip(self.linears, self.bns, self.pl):
             N, K = pl.N, pl.K
             y = torch.empty(B, ceil_to(N, 8), dtype=adt, device=dev)
             st = BNState(N, dev)
             # a hidden BN layer on the wave-specialised kernel: its producers also write the operand AFTER the prologue (the previous
             # layer's post-activation, 2 bytes per element), which lets this layer's dW GEMM run the plain LDS-DMA kernel instead of
-            # redoing the prologue on its Q operand (EncoderB's second Linear: 52 -> 30 us for the dW GEMM)
+            # redoing the prologue on its Q operand (EncoderB's second Linear: 52 -> 39 us for the dW GEMM)
             h_act = None
             if want_bwd and pro is not None and ops.can_keep_pro_out(prec, B, N, K, h, y) and pro[2] is not None \
                     and pro[2].stride(0) % 8 == 0 and pro[2].data_ptr() % 8 == 0:
                 h_act = torch.empty(B, K, dtype=torch.bfloat16, device=dev)
             if train:
                 stats = stats_bufs[len(saved)] if stats_bufs is not None else torch.zeros(2, N, dtype=torch.float64, device=dev)
-                try:
-                    ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd", pro_out=h_act)
-                except RuntimeError:
-                    if h_act is None:
-                        raise
-                    # the library did not take the problem on the kernel that writes pro_out (the argument check fails BEFORE anything
-                    # is enqueued): the ordinary call, and the backward redoes the prologue on its operand load
-                    h_act = None
-                    ops.gemm_nt(prec, h, pl.w, N, K, y, bias=pl.bias, prologue=pro, stats=stats, tag=f"{self.name}.L{len(saved)}.fwd")
-                ops.bn_finalize(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
-                                bn.momentum if bn.momentum is not None else 0.1)
+                h_act = consume(N, K, y, pl.bias, pl.w, f"{self.name}.L{len(saved)}.fwd", stats=stats, pro_out=h_act)
+                # the finalisation of THIS layer's statistics is owed to whoever reads y next (the next layer or the heads)
+                fin = ops.bn_finalize_args(B, N, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, bn.eps,
+                                           bn.momentum if bn.momentum is not None else 0.1)
                 mask = masks[len(saved)]
                 new_pro = (st.scale, st.shift, mask, 1.0 / (1.0 - DROP_P))
             else:
@@ -221,7 +239,7 @@ class EncoderMLP:
             saved.append((h, pro, y, st, new_pro) if h_act is None else (h_act, None, y, st, new_pro))      # backward's Q operand: plain when kept
             h, pro = y, new_pro
         heads = torch.empty(B, 2 * self.latent, dtype=torch.float32, device=dev)
-        ops.gemm_nt(prec, h, self.pl_heads.w, 2 * self.latent, self.pl_heads.K, heads, bias=self.pl_heads.bias, prologue=pro, tag=f"{self.name}.heads.fwd")
+        consume(2 * self.latent, self.pl_heads.K, heads, self.pl_heads.bias, self.pl_heads.w, f"{self.name}.heads.fwd")
         return heads, saved
 
     def backward(self, prec, saved, d_heads, grads, tn=ops.gemm_tn, stats_bufs=None, train=True, d_heads_lp=None):

@@ -206,7 +206,8 @@ def can_keep_pro_out(prec, M, N, K, a, out):
 
 
 def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=False, prologue=None,
-            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, loss_sum=None, tag=None, pro_out=None):
+            epilogue=EPI_STORE, h=None, bn=None, bn_coef=None, bn_phase=None, stats=None, loss_sum=None, tag=None, pro_out=None,
+            pro_finalize=None):
     """out[M,N] = epi( pro(a)[M,K] @ W[N,K]^T ).  prologue = (scale, shift, mask|None, inv_keep);
     bn = (scale, shift, mean, rstd, mask|None, inv_keep) for EPI_BN_BWD (out=None, stats given:
     statistics phase; out and bn_coef given: apply phase).  stats: zeroed float64 [2][N] accumulator.
@@ -226,6 +227,8 @@ def gemm_nt(prec, a, w_lp, N, K, out, *, bias=None, act=ACT_NONE, accumulate=Fal
         g.pro_inv_keep = inv_keep
         if pro_out is not None:                 # the operand after the prologue (bf16 [M][>= K]); see can_keep_pro_out()
             g.pro_out, g.ld_pro_out = pro_out.data_ptr(), _ld(pro_out)
+        if pro_finalize is not None:            # BnFinalizeArgs of the layer that produced `a` (bn_finalize_args()): finalised inside this launch
+            g.pro_finalize = C.addressof(pro_finalize)
     g.w, g.ldw = w_lp.data_ptr(), w_lp.stride(0)
     g.epilogue = epilogue
     if out is not None:
@@ -332,14 +335,20 @@ def gemm_tn(prec, p, q, dw, db, N, K, *, q_prologue=None, p_prologue=None, nspli
 # --------------------------------------------------------------------------------------------
 # BatchNorm pieces
 # --------------------------------------------------------------------------------------------
-def bn_finalize(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
-                eps=BN_EPS, momentum=BN_MOMENTUM):
+def bn_finalize_args(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
+                     eps=BN_EPS, momentum=BN_MOMENTUM):
+    """The argument struct of mmvae_bn_finalize: launched on its own (bn_finalize) or handed to the consumer GEMM (gemm_nt(pro_finalize=))."""
     if M < 2:
         # same failure mode as torch.nn.BatchNorm1d in training mode
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{M}, {N}]")
-    a = L.BnFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
-                         gamma.data_ptr(), beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
-                         mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    return L.BnFinalizeArgs(M, N, stats[0].data_ptr(), stats[1].data_ptr(),
+                            gamma.data_ptr(), beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
+                            mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+
+
+def bn_finalize(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift,
+                eps=BN_EPS, momentum=BN_MOMENTUM, args=None):
+    a = args if args is not None else bn_finalize_args(M, N, stats, gamma, beta, running_mean, running_var, nbt, mean, rstd, scale, shift, eps, momentum)
     L.check(L.load().mmvae_bn_finalize(C.byref(a), _stream()), "mmvae_bn_finalize")
 
 
