@@ -77,7 +77,11 @@ __device__ unsigned long long mm_stamps_tn[12];
 // are moved by LDS-DMA (global_load_lds_dwordx4, 4 rows x 256 B per wave-instruction, the chunk swizzle applied to the SOURCE
 // address) instead of global -> VGPR -> ds_write; the registers -> LDS pass was what the MFMAs of this kernel waited for
 // (tools/stamp_tn.py: stage 24 % of a step + the fragment step that follows it stalled on it).
-template <typename CT, typename PSrc, typename QSrc, bool DMA = false>
+// NG = 2 (DMA form only): EIGHT waves in two groups of four; every wave still owns a 64x64 piece of the 128x128 tile, group g
+// multiplies rows [32 g, 32 g + 32) of every 64-row step and the two partial tiles are added through LDS before the slab
+// store -- twice the rows per workgroup at the same number of waves per CU, i.e. HALF the slab (its store + the reduce's
+// read were 67 MB next to 100 MB of operands for a 512x256 dW at batch 65 536).
+template <typename CT, typename PSrc, typename QSrc, bool DMA = false, int NG = 1>
 __device__ __forceinline__
 void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
              int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab,
@@ -100,8 +104,9 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
     const int m_end = min(M, m_begin + rows_per_split);
     if (m_begin >= m_end) return;
 
+    static_assert(NG == 1 || (NG == 2 && DMA), "two wave groups: DMA form only");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = (wid & 3) >> 1, wc = wid & 1;
 
     if (QSrc::NEEDS_AUX) qs.init(aux, tid, k0);
     if (PSrc::NEEDS_AUX) ps.init(auxp, tid, n0);
@@ -234,6 +239,44 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
                 __builtin_amdgcn_global_load_lds((gbl_void*)gq, (lds_void*)(sQ + p * 1024), 16, 0, 0);
             }
         };
+        if constexpr (NG == 2) {
+            // One workgroup per CU: a ring of FOUR 64-row buffers, three steps under way while one is multiplied (with one step
+            // ahead a lone workgroup had 32 KB in flight per CU and waited for the trip from HBM in every step).  Issued from
+            // inline assembly and waited for by counted vmcnt (see tnw_dma16 in gemm_tn_wide.hip for why not the builtin);
+            // the ring is unrolled so that every buffer is a compile-time offset.
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+            auto dma16 = [&](const void* g, unsigned lds_addr) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(g) : "memory");     // nothing else here uses m0
+            };
+            auto issue4 = [&](int t, int slot) {
+                const unsigned sP = lds0 + slot * BUF, sQ = sP + G::MT * G::ROWB;
+                const int m0 = m_begin + t * G::MT;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int p = wv + 8 * i, r = p * 4 + prow;
+                    const int ch = (((ppos >> 1) ^ G::f(r)) << 1) | (ppos & 1);
+                    const unsigned rp_ = (unsigned)(m0 + r);
+                    dma16(ps.p + (rp_ * (unsigned)ps.lda + (unsigned)min(n0 + ch * 8, ncap)), sP + p * 1024);
+                    dma16(qs.p + (rp_ * (unsigned)qs.lda + (unsigned)min(k0 + ch * 8, kcap)), sQ + p * 1024);
+                }
+            };
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) if (s_ < nt) issue4(s_, s_);
+            for (int t0 = 0; t0 < nt; t0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u;
+                    if (t >= nt) break;
+                    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // steps t + 1, t + 2 (4 transfers each) may still be under way
+                    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                // everybody's pieces of step t have landed; nobody still reads step t - 1
+                    asm volatile("" ::: "memory");
+                    if (t + 3 < nt) issue4(t + 3, (u + 3) & 3);  // into the buffer step t - 1 was read from
+                    compute(u, wv >> 2);                         // (fragment registers double-buffered across steps: measured 1-3 us slower)
+                }
+            }
+        } else {
         issue(0, 0);
         for (int t = 0; t < nt; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own pieces of tile t have landed
@@ -241,6 +284,33 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
             if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
             compute(t & 1, 0);
             compute(t & 1, 1);
+        }
+        }
+        if constexpr (NG == 2) {
+            // group 1's partial tile (+ its column sums of P) -> LDS -> added by group 0, which stores
+            __syncthreads();                                     // the ring is free
+            float* red = (float*)smem + (wid & 3) * 4096;        // 16 KB per wave pair, 16 bytes per lane and accumulator: conflict-free
+            float* redb = (float*)(smem + 2 * BUF) + (wid & 3) * 256;            // behind the 64 KB of partial tiles, inside the (free) ring
+            if (wv >> 2) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) *(f32x4*)(red + ((a * 4 + b) * 64 + lane) * 4) = acc[a][b];
+                if (do_bias) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) redb[a * 64 + lane] = bsum[a];
+                }
+            }
+            __syncthreads();
+            if (wv >> 2) return;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += *(const f32x4*)(red + ((a * 4 + b) * 64 + lane) * 4);
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) bsum[a] += redb[a * 64 + lane];
+            }
         }
     } else if constexpr (!TWO_SETS) {
         fetch(rp0, rq0, 0);
@@ -331,13 +401,13 @@ void tn_body(const PSrc& ps, const QSrc& qs, float* __restrict__ dW, long ldw, f
 #endif
 }
 
-template <typename CT, typename PSrc, typename QSrc, bool DMA>
-__global__ __launch_bounds__(NTHREADS, 2)
+template <typename CT, typename PSrc, typename QSrc, bool DMA, int NG = 1>
+__global__ __launch_bounds__(NTHREADS * NG, NG == 2 ? 1 : 2)
 void gemm_tn_kernel(PSrc ps, QSrc qs, float* __restrict__ dW, long ldw, float* __restrict__ db,
                     int M, int N, int K, int ntk, int ntiles, int nsplit, int rows_per_split, float* __restrict__ slab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 buffers + 4 KiB prologue scale/shift
-    tn_body<CT, PSrc, QSrc, DMA>(ps, qs, dW, ldw, db, M, N, K, ntk, ntiles, nsplit, rows_per_split, slab, (int)blockIdx.x, smem);
+    tn_body<CT, PSrc, QSrc, DMA, NG>(ps, qs, dW, ldw, db, M, N, K, ntk, ntiles, nsplit, rows_per_split, slab, (int)blockIdx.x, smem);
 }
 
 template <typename T> struct TnPlainBf16 { static constexpr bool value = false; };
@@ -456,7 +526,7 @@ static int tn_reduce(const mmvae_gemm_tn_args* a, int nsplit, hipStream_t st) {
     return 0;
 }
 
-static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int& ntiles, int& nsplit, int& rps) {
+static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int& ntiles, int& nsplit, int& rps, int wg_target = 512) {
     const int ntn = (N + TILE - 1) / TILE;
     ntk = (K + TILE - 1) / TILE; ntiles = ntn * ntk;
     nsplit = nsplit_req;
@@ -464,7 +534,7 @@ static void tn_split(int M, int N, int K, int MT, int nsplit_req, int& ntk, int&
         // ONE resident round: at most 2 workgroups per CU (512) in total and -- because split z runs on XCD z % 8 --
         // a multiple of 8 splits so that every XCD gets the same share (a 520-block grid costs a whole extra round).
         // Every split adds one f32 atomic per output element; keep at least 4 m-tiles of work per workgroup.
-        nsplit = 512 / ntiles;
+        nsplit = wg_target / ntiles;
         if (nsplit >= 8) nsplit &= ~7;
         int max_split = (M + 4 * MT - 1) / (4 * MT);
         if (nsplit > max_split) nsplit = max_split;
@@ -484,6 +554,32 @@ static int launch_tn(const mmvae_gemm_tn_args* a, const PSrc& ps, const QSrc& qs
     float* slab = tn_use_slab(a, nsplit) ? a->slab : nullptr;
     constexpr int LDS = 4 * G::MT * G::ROWB + 4096 + 4096;
     if constexpr (sizeof(CT) == 2 && TnPlainBf16<PSrc>::value && TnPlainBf16<QSrc>::value) {
+        // Two wave groups (one 8-wave workgroup per CU, half the slab) when an automatic split fills the chip that way: whole
+        // multiples of 8 splits (XCD balance) on >= 7/8 of the CUs -- 8 or 7 tiles (512x256, 256x512, 782x128: 36-38 against 40-41 us
+        // with the reduce).  The 20 tiles of 572x512 would make 160 workgroups, or 240 with 12 splits of which the last four are
+        // shared by two XCDs each (tried: 69 against 64-65 us alone, the same inside the step).
+        static const int ng_env = getenv("MMVAE_TN_NG") ? atoi(getenv("MMVAE_TN_NG")) : 0;      // A/B switch: 1 / 2 = never / always
+        bool two = false;
+        if (tn_dma_ok(a->M, G::MT) && ng_env != 1) {
+            tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps, 256);
+            two = ng_env == 2 || (a->nsplit <= 0 && nsplit % 8 == 0 && nsplit * ntiles >= 224);
+            if (!two) tn_split(a->M, a->N, a->K, G::MT, a->nsplit, ntk, ntiles, nsplit, rps);
+        }
+        if (two) {
+            const int grid2 = ((nsplit + 7) / 8) * 8 * ntiles;
+            float* slab2 = tn_use_slab(a, nsplit) ? a->slab : nullptr;
+            constexpr int LDS2 = 8 * G::MT * G::ROWB + 4096;          // four 64-row P + Q buffers
+            static bool attr_dma2 = false;
+            if (!attr_dma2) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<CT, PSrc, QSrc, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                if (e != hipSuccess) return (int)e;
+                attr_dma2 = true;
+            }
+            hipLaunchKernelGGL((gemm_tn_kernel<CT, PSrc, QSrc, true, 2>), dim3(grid2), dim3(NTHREADS * 2), LDS2, st, ps, qs,
+                               a->dw, a->lddw, a->db, a->M, a->N, a->K, ntk, ntiles, nsplit, rps, slab2);
+            MM_CHECK_LAUNCH();
+            return slab2 ? tn_reduce(a, nsplit, st) : 0;
+        }
         if (tn_dma_ok(a->M, G::MT)) {
             static bool attr_dma = false;
             if (!attr_dma) {
