@@ -13,7 +13,7 @@ ga = torch.empty(B, 784, dtype=torch.bfloat16, device=dev); gb = torch.empty(B, 
 lg = torch.randn(B, S, device=dev); site = torch.randint(0, S, (B,), device=dev); gc = torch.empty(B, S, device=dev)
 mu, lv = torch.randn(B, Lz, device=dev), torch.randn(B, Lz, device=dev); gmu, glv = torch.empty_like(mu), torch.empty_like(lv)
 big = torch.empty(1 << 28, device=dev)
-sums = torch.zeros(4, dtype=torch.float64, device=dev)
+sums = torch.zeros(5, dtype=torch.float64, device=dev)
 parts = {
     "mse": dict(recon_a=xa, a=ta, g_a=ga),
     "bce": dict(recon_b=xb, b=tb, g_b=gb, grad_b_wrt_logit=True),
@@ -21,9 +21,11 @@ parts = {
     "kl": dict(mu=mu, logvar=lv, g_mu=gmu, g_lv=glv),
 }
 parts["mse+bce"] = {**parts["mse"], **parts["bce"]}
+parts["ce+kl"] = {**parts["ce"], **parts["kl"]}
 parts["all"] = {k: v for p in (parts["mse"], parts["bce"], parts["ce"], parts["kl"]) for k, v in p.items()}
 bytes_ = {"mse": B * A * 10, "bce": B * D * 10, "ce": B * S * 8, "kl": B * Lz * 16}
 bytes_["mse+bce"] = bytes_["mse"] + bytes_["bce"]
+bytes_["ce+kl"] = bytes_["ce"] + bytes_["kl"]
 bytes_["all"] = bytes_["mse+bce"] + bytes_["ce"] + bytes_["kl"]
 for name, kw in parts.items():
     ts = []

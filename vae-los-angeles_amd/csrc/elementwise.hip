@@ -424,15 +424,66 @@ __device__ __forceinline__ float bce_part(const mmvae_loss_args& a, long tid0, l
     return a.grad_b_wrt_logit ? bce_part_g<GT, V, true>(a, tid0, stride) : bce_part_g<GT, V, false>(a, tid0, stride);
 }
 
-template <typename GT, int VA, int VD>
-__global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
+// TAIL: the class + KL terms alone (the reconstruction terms run inside the decoder GEMMs).  The launch is then a few dependent
+// HBM round trips and nothing else, so everything a thread will need is requested up front: the KL operands (KL_U elements)
+// BEFORE the class rows are walked, and CE_U rows per half wave at a time -- at B = 65 536 on 512 workgroups that is one round
+// trip for the KL term and two for the class term instead of three + four one after the other (26 -> 14 us).
+// ce_vec (S % 4 == 0, S <= 32, 16-byte aligned rows): the class term as ONE ROW PER THREAD -- S / 4 16-byte loads, max, one exp
+// per logit kept in registers, S / 4 16-byte gradient stores -- instead of a row per half wave, whose two 5-step butterflies + the
+// label pick are eleven DEPENDENT ds_bpermute round trips per row (~1 500 cycles; 17 of this launch's 25 us at B = 65 536).
+template <typename GT, int VA, int VD, bool TAIL = false>
+__global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a, int ce_vec) {
     if (a.beta_gamma_dev) { a.beta = a.beta_gamma_dev[0]; a.gamma = a.beta_gamma_dev[1]; }     // hyper-parameters a captured graph can change
     const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     float n_bad = 0.f;
-    if (a.recon_a) s[0] = mse_part<GT, VA>(a, tid0, stride);
-    if (a.recon_b) s[1] = bce_part<GT, VD>(a, tid0, stride);
-    if (a.logits && a.S <= 32) {
+    if (!TAIL && a.recon_a) s[0] = mse_part<GT, VA>(a, tid0, stride);
+    if (!TAIL && a.recon_b) s[1] = bce_part<GT, VD>(a, tid0, stride);
+    constexpr int KL_U = TAIL ? 10 : 4;
+    const long total = a.mu ? (long)a.B * a.L : 0;
+    float mu0[KL_U], lv0[KL_U];
+    if (TAIL && a.mu) {
+#pragma unroll
+        for (int u = 0; u < KL_U; ++u) { const long i = min(tid0 + u * stride, total - 1); mu0[u] = a.mu[i]; lv0[u] = a.logvar[i]; }
+    }
+    if (a.logits && ce_vec) {
+        const int nv = a.S >> 2;
+        for (long r = tid0; r < a.B; r += stride) {
+            const f32x4* lp = (const f32x4*)(a.logits + r * a.ld_logits);
+            f32x4 x[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = c < nv ? lp[c] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            long y = a.site[r];
+            const bool ign = y == -100;                      // ignore_index, as below
+            const bool bad = !ign && (y < 0 || y >= a.S);
+            if (bad || ign) y = 0;
+            const float w = ign ? 0.f : (a.class_weights ? a.class_weights[y] : 1.f);
+            float m = -INFINITY, xy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { m = fmaxf(m, x[c][j]); xy = (c * 4 + j == (int)y) ? x[c][j] : xy; }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float e = c < nv ? expf(x[c][j] - m) : 0.f; x[c][j] = e; se += e; }
+            s[2] += w * (m + logf(se) - xy);
+            if (bad) n_bad += 1.f;
+            if (a.g_c) {
+                f32x4* gp = (f32x4*)(a.g_c + r * a.ld_gc);
+                const float gw = a.gamma * w;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c >= nv) break;
+                    f32x4 g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = gw * (x[c][j] / se - (c * 4 + j == (int)y ? 1.f : 0.f));
+                    gp[c] = g;
+                }
+            }
+        }
+    } else if (a.logits && a.S <= 32) {
         // Class term, one row per HALF wave (lane j of the half holds logit j): the row is one coalesced 4 S-byte read, max and
         // sum are 5-step shuffles, ONE exp per logit serves the loss and the gradient.  (One thread per row -- 24 strided loads
         // and two exp per logit in a serial loop -- took 25 us of the 35 this kernel needs once the reconstruction terms run
@@ -441,7 +492,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
         const long wave0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2, wstride = (long)gridDim.x * (blockDim.x >> 6) * 2;
         // CE_U rows per half wave are requested before the first is reduced: the loop is a chain of dependent HBM round trips
         // otherwise (8 per wave at B = 65 536 and 1024 workgroups: 20 of this kernel's 34 us)
-        constexpr int CE_U = 4;
+        constexpr int CE_U = TAIL ? 8 : 4;
         for (long r0 = wave0; r0 < a.B; r0 += wstride * CE_U) {    // wave-uniform trip count
             float xs[CE_U]; long ys[CE_U];
 #pragma unroll
@@ -496,12 +547,15 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(mmvae_loss_args a) {
     if (a.mu) {
         // KL_U elements per thread are loaded before any is processed: the gradient stores may alias the next loads as far as the
         // compiler knows, and one element per iteration made this a chain of dependent round trips (13 us for 21 MB)
-        constexpr int KL_U = 4;
-        const long total = (long)a.B * a.L;
         for (long i0 = tid0; i0 < total; i0 += stride * KL_U) {
             float mu[KL_U], lv[KL_U];
+            if (TAIL && i0 == tid0) {
 #pragma unroll
-            for (int u = 0; u < KL_U; ++u) { const long i = min(i0 + u * stride, total - 1); mu[u] = a.mu[i]; lv[u] = a.logvar[i]; }
+                for (int u = 0; u < KL_U; ++u) { mu[u] = mu0[u]; lv[u] = lv0[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KL_U; ++u) { const long i = min(i0 + u * stride, total - 1); mu[u] = a.mu[i]; lv[u] = a.logvar[i]; }
+            }
 #pragma unroll
             for (int u = 0; u < KL_U; ++u) {
                 const long i = i0 + u * stride;
@@ -832,7 +886,15 @@ static int launch_loss(const mmvae_loss_args* a, hipStream_t st) {
     // class / KL terms alone (reconstruction terms inside the decoder GEMMs): every workgroup ends in f64 atomics on the same few
     // addresses; with the row and element loops unrolled 512 workgroups are enough to cover the latency and halve that tail
     if (!a->recon_a && !a->recon_b && grid > 512) grid = 512;
-#define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a)
+#define MM_LOSS(VA, VD) hipLaunchKernelGGL((vae_loss_kernel<GT, VA, VD>), dim3(grid), dim3(256), 0, st, *a, ce_vec ? 1 : 0)
+    static const int tail_env = getenv("MMVAE_LOSS_TAIL") ? atoi(getenv("MMVAE_LOSS_TAIL")) : 2;          // A/B switch: 0 general form, 1 without ce_vec
+    const bool ce_vec = tail_env == 2 && a->logits && a->S <= 32 && a->S % 4 == 0 && a->ld_logits % 4 == 0 && ((uintptr_t)a->logits & 15) == 0 &&
+                        (!a->g_c || (a->ld_gc % 4 == 0 && ((uintptr_t)a->g_c & 15) == 0));
+    if (tail_env && !a->recon_a && !a->recon_b) {
+        // every workgroup ends in f64 atomics on the same addresses (~13 ns each, one after the other): a row per thread, no more
+        if (ce_vec) grid = (int)std::min<long>(512, (a->B + 255) / 256);
+        hipLaunchKernelGGL((vae_loss_kernel<GT, 1, 1, true>), dim3(grid), dim3(256), 0, st, *a, ce_vec ? 1 : 0);
+    } else
     if (va == 4 && vd == 4) MM_LOSS(4, 4); else if (va == 4 && vd == 2) MM_LOSS(4, 2); else if (va == 4) MM_LOSS(4, 1);
     else if (va == 2 && vd == 4) MM_LOSS(2, 4); else if (va == 2 && vd == 2) MM_LOSS(2, 2); else if (va == 2) MM_LOSS(2, 1);
     else if (vd == 4) MM_LOSS(1, 4); else if (vd == 2) MM_LOSS(1, 2); else MM_LOSS(1, 1);
