@@ -22,6 +22,10 @@
 #include "mmvae_hip.h"
 #include "gemm_src.h"
 
+#ifndef MM_REDUCE_U
+#define MM_REDUCE_U 16      // loads a reduce thread keeps in flight (step at B = 65 536: 4 -> +8 us, 8 -> +2.5, 32 -> +8.5 against 16)
+#endif
+
 namespace mm {
 
 template <typename CT> struct TnGeom;
@@ -465,6 +469,21 @@ void gemm_tn_group_kernel(const TnGroup g)
     }
 }
 
+// sum_z p[z * stride], z = 0 .. n-1, added in that order; U loads are requested before the first is added (a thread of a reduce
+// launch has nothing else to do; MM_REDUCE_U = 16 measured best)
+template <int U>
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, long stride, int n) {
+    float s = 0.f;
+    for (int z = 0; z < n; z += U) {
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = (z + u < n) ? p[(long)(z + u) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += t[u];
+    }
+    return s;
+}
+
 // dW_p[n][k] += sum_z slab_p[z][n][k] for every problem of a group, fixed order (bitwise reproducible)
 struct TnGroupReduce { const float* slab[MMVAE_TN_GROUP_MAX]; float* dW[MMVAE_TN_GROUP_MAX]; int nsplit[MMVAE_TN_GROUP_MAX]; int nk[MMVAE_TN_GROUP_MAX];
                        int first[MMVAE_TN_GROUP_MAX + 1]; int n; };
@@ -476,10 +495,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupReduc
     for (int j = 1; j < MMVAE_TN_GROUP_MAX; ++j) if (j < g.n && i >= g.first[j]) pi = j;
     const int e = i - g.first[pi], nk = g.nk[pi], ns = g.nsplit[pi];
     const float* sl = g.slab[pi] + e;
-    float s = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < ns; ++z) s += sl[(long)z * nk];
-    g.dW[pi][e] += s;                                    // lddw == K for these (contiguous gradient views)
+    g.dW[pi][e] += slab_sum<MM_REDUCE_U>(sl, nk, ns);                                   // lddw == K for these (contiguous gradient views)
 }
 
 #ifdef MM_STAMP
@@ -500,9 +516,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const int z0 = blockIdx.y * TN_RG, z1 = min(nsplit, z0 + TN_RG);
     const bool single = gridDim.y == 1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int z = z0; z < z1; ++z) s += slab[z * nk + i];          // independent loads: 8 in flight per thread
+        const float s = slab_sum<MM_REDUCE_U>(slab + z0 * nk + i, nk, z1 - z0);
         const long n = i / K, k = i - n * K;
         if (single) dW[n * ldw + k] += s;
         else unsafeAtomicAdd(dW + n * ldw + k, s);
