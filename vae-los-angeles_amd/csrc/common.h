@@ -106,8 +106,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct Philox {
     static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
         const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        // ONE 32 x 32 -> 64-bit multiply-add (v_mad_u64_u32) per product: written as __umulhi + a 32-bit product hipcc emits
+        // v_mul_hi_u32 + v_mul_lo_u32 (the noise launch is bound by its multiplies; step -2.6 us)
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c[0], p1 = (uint64_t)M1 * (uint64_t)c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
         c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     }
