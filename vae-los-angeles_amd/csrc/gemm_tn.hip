@@ -474,13 +474,22 @@ void gemm_tn_group_kernel(const TnGroup g)
 template <int U>
 __device__ __forceinline__ float slab_sum(const float* __restrict__ p, long stride, int n) {
     float s = 0.f;
-    for (int z = 0; z < n; z += U) {
-        float t[U];
+    int z = 0;
+    for (; z + U <= n; z += U) {                    // whole batches without predicates (n is small for the big matrices:
+        float t[U];                                 //  per-load predication cost them +11 us per launch at the scaled widths)
 #pragma unroll
-        for (int u = 0; u < U; ++u) t[u] = (z + u < n) ? p[(long)(z + u) * stride] : 0.f;
+        for (int u = 0; u < U; ++u) t[u] = p[(long)(z + u) * stride];
 #pragma unroll
         for (int u = 0; u < U; ++u) s += t[u];
     }
+    for (; z + 4 <= n; z += 4) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = p[(long)(z + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += t[u];
+    }
+    for (; z < n; ++z) s += p[(long)z * stride];
     return s;
 }
 
