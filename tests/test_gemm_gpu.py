@@ -101,6 +101,36 @@ def test_tn(prec, M, N, K):
     assert float((dw.cpu().double() - ref - 1).abs().max()) <= 2e-5 * np.sqrt(M) * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 256), (16384, 500, 250), (8192, 782, 128), (12288, 256, 512)])
+def test_tn_two_wave_groups(M, N, K):
+    """Plain bf16 x bf16 dW problems whose automatic split fills the chip with ONE 8-wave workgroup per CU (8 or 7 output tiles,
+    batch >= 8192) run gemm_tn_kernel<.., DMA, NG = 2>: two wave groups, 4-buffer DMA ring, partial tiles added through LDS.
+    Against the fp64 product of the same bf16 operands, and against the 4-wave form (an explicit split count selects it)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    P = _round(torch.randn(M, N, generator=g), PREC_BF16)
+    Q = _round(torch.randn(M, K, generator=g), PREC_BF16)
+    ref = P.double().t() @ Q.double()
+    refb = P.double().sum(0)
+    def mk(X):
+        t = torch.full((M, ops.ceil_to(X.shape[1], 8)), 7.0, dtype=torch.bfloat16, device=DEV)       # pad columns must not leak in
+        t[:, :X.shape[1]] = X.to(DEV)
+        return t
+    Pd, Qd = mk(P), mk(Q)
+    slab = torch.empty(1 << 24, device=DEV)
+    got = {}
+    for nsplit in (0, 64):
+        dw = torch.ones(N, K, device=DEV); db = torch.ones(N, device=DEV)                            # accumulates into what is there
+        ops.gemm_tn(PREC_BF16, Pd, Qd, dw, db, N, K, nsplit=nsplit, slab=slab)
+        tol = 2e-5 * np.sqrt(M) * float(ref.abs().max())
+        assert float((dw.cpu().double() - 1 - ref).abs().max()) <= tol, nsplit
+        assert float((db.cpu().double() - 1 - refb).abs().max()) <= 2e-5 * np.sqrt(M) * float(refb.abs().max()) + 1e-4, nsplit
+        got[nsplit] = dw.clone()
+        dw2 = torch.ones(N, K, device=DEV); db2 = torch.ones(N, device=DEV)
+        ops.gemm_tn(PREC_BF16, Pd, Qd, dw2, db2, N, K, nsplit=nsplit, slab=slab)
+        assert torch.equal(dw, dw2), nsplit                                                            # fixed-order sums: bitwise reproducible
+    assert float((got[0] - got[64]).abs().max()) <= 1e-5 * np.sqrt(M) * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("prec", [PREC_F32, PREC_BF16])
 @pytest.mark.parametrize("with_mask", [True, False])
 def test_bn_relu_drop_prologue_and_bwd_epilogues(prec, with_mask):

@@ -228,11 +228,12 @@ def test_loss_epilogue_against_store_epilogue_plus_loss_kernel(M, N, K, bce):
         ops.gemm_nt(PREC_BF16, A[:, :64].contiguous(), pl.w, N, 64, g_new, bias=pl.bias, epilogue=ops.EPI_LOSS_MSE, h=T, loss_sum=sums2[0:1])
 
 
-@pytest.mark.parametrize("S,weighted", [(24, False), (24, True), (40, True)])
+@pytest.mark.parametrize("S,weighted", [(24, False), (24, True), (22, True), (8, False), (32, True), (40, True)])
 def test_class_term_ignore_index(S, weighted):
     """F.cross_entropy's default ignore_index = -100 (losses.py:39 passes none): such a row adds no loss and gets a zero gradient in
     the reference; here it must not count as an out-of-range label either.  Against torch's own cross_entropy on the same logits
-    (both class-term code paths: S <= 32 one row per half wave, S > 32 one row per thread)."""
+    (all three class-term code paths: S % 4 == 0 and <= 32 one row per thread with 16-byte loads, other S <= 32 one row per half
+    wave, S > 32 one row per thread, scalar loads)."""
     B = 777
     g = torch.Generator().manual_seed(S)
     logits = torch.randn(B, S, generator=g)
@@ -250,3 +251,27 @@ def test_class_term_ignore_index(S, weighted):
     np.testing.assert_allclose(sums[2].item(), ref.item(), rtol=2e-6)
     np.testing.assert_allclose(gc.cpu().numpy(), lr.grad.numpy(), atol=2e-6)
     assert float(gc[::7].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S", [24, 22])
+def test_class_term_out_of_range_labels_are_counted(S):
+    """A label outside [0, S) (torch device-asserts on it) is counted in sums[4] and treated as class 0, the same way on the
+    row-per-thread (S = 24) and the row-per-half-wave (S = 22) forms of the class term."""
+    B = 515
+    g = torch.Generator().manual_seed(3 * S)
+    logits = torch.randn(B, S, generator=g)
+    site = torch.randint(0, S, (B,), generator=g)
+    bad = torch.arange(5, B, 37)
+    site_bad = site.clone(); site_bad[bad] = S + 3
+    site_bad[bad[::2]] = -1
+    site_ref = site.clone(); site_ref[bad] = 0
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, site_ref, reduction="sum")
+    ref.backward()
+    ld = logits.to(DEV)
+    gc = torch.full_like(ld, 7.0)
+    sums = torch.zeros(5, dtype=torch.float64, device=DEV)
+    ops.vae_loss(B, logits=ld, site=site_bad.to(DEV), gamma=0.5, sums=sums, g_c=gc)
+    assert sums[4].item() == float(len(bad))
+    np.testing.assert_allclose(sums[2].item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(gc.cpu().numpy(), 0.5 * lr.grad.numpy(), atol=2e-6)
