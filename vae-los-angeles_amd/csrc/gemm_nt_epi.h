@@ -353,7 +353,8 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
                     const uint32_t l0 = ops.h[m * NG + 2 * p][q], l1 = ops.h[m * NG + 2 * p + 1][q];
                     hw[0][q] = l0; hw[1][q] = l1;
                     if (h_lines) {                              // loaded in full-line layout: swap back (see epi_h_lines)
-                        const uint32_t got = (uint32_t)__shfl_xor((int)((l1 & low) | (l0 & ~low)), 8, 64);
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)((l1 & low) | (l0 & ~low)), 0x128, 0xf, 0xf, true);   // row_ror:8 == lane li ^ 8: one VALU op (
+                                                                                                                                   // __shfl_xor is a ds_bpermute round trip)
                         hw[0][q] = (l0 & low) | (got & ~low);
                         hw[1][q] = (got & low) | (l1 & ~low);
                     }
@@ -431,7 +432,7 @@ __device__ __forceinline__ void nt_epilogue_body(const float* ecol, f32x4 (&acc)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t send = (pk[1][q] & low) | (pk[0][q] & ~low);
-                    const uint32_t got = (uint32_t)__shfl_xor((int)send, 8, 64);
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x128, 0xf, 0xf, true);             // row_ror:8 == lane li ^ 8
                     st0[q] = (pk[0][q] & low) | (got & ~low);        // rows m*16 + (li & 7):     own first half | row li-8's second half
                     st1[q] = (got & low) | (pk[1][q] & ~low);        // rows m*16 + 8 + (li & 7): row li+8's first half | own second half
                 }
