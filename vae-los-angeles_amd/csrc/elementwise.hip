@@ -192,35 +192,49 @@ __global__ __launch_bounds__(256) void embed_table_bwd_kernel(int S, int E, int 
     float* dT = sm;                                      // [S][2L]: the copies of the table gradient summed (fixed order)
     float* sE = dT + S * L2;                             // [S][E]
     float* sW = sE + S * E;                              // [2L][E]: w_mu rows, then w_lv rows
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    // one index space [dEmb | dWcat | db]: the three products run side by side
+    const int n0 = S * E, n1 = n0 + L2 * E, n2 = n1 + L2;
+    auto dst_of = [&](int i) -> float* {
+        if (i < n0) return d_emb + i;
+        if (i < n1) { const int k = i - n0, j = k / E, e = k - j * E; return j < L ? d_w_mu + (long)j * E + e : d_w_lv + (long)(j - L) * E + e; }
+        const int j = i - n1;
+        return j < L ? d_b_mu + j : d_b_lv + (j - L);
+    };
+    // the gradient element this thread adds to is requested together with the operands: behind the products it was one more
+    // dependent round trip of a launch that is nothing but round trips
+    float* const dst0 = t0 < n2 ? dst_of(t0) : nullptr;
+    const float old0 = dst0 ? *dst0 : 0.f;
     for (int i = threadIdx.x; i < S * L2; i += blockDim.x) {
+        float c8[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) c8[c] = c < copies ? dTc[(long)c * S * L2 + i] : 0.f;
         float v = 0.f;
-        for (int c = 0; c < copies; ++c) v += dTc[(long)c * S * L2 + i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v += c8[c];
+        for (int c = 8; c < copies; ++c) v += dTc[(long)c * S * L2 + i];
         dT[i] = v;
     }
     for (int i = threadIdx.x; i < S * E; i += blockDim.x) sE[i] = emb[i];
     for (int i = threadIdx.x; i < L2 * E; i += blockDim.x) sW[i] = i < L * E ? w_mu[i] : w_lv[i - L * E];
     __syncthreads();
-    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    // one index space [dEmb | dWcat | db]: the three products run side by side
-    const int n0 = S * E, n1 = n0 + L2 * E, n2 = n1 + L2;
     for (int i = t0; i < n2; i += nt) {
         float acc = 0.f;
         if (i < n0) {                                    // dEmb = dT x Wcat
             const int s = i / E, e = i - s * E;
 #pragma unroll 4
             for (int j = 0; j < L2; ++j) acc += dT[s * L2 + j] * sW[j * E + e];
-            d_emb[i] += acc;
         } else if (i < n1) {                             // dWcat = dT^T x emb
             const int k = i - n0, j = k / E, e = k - j * E;
 #pragma unroll 4
             for (int s = 0; s < S; ++s) acc += dT[s * L2 + j] * sE[s * E + e];
-            if (j < L) d_w_mu[(long)j * E + e] += acc; else d_w_lv[(long)(j - L) * E + e] += acc;
         } else {
             const int j = i - n1;
 #pragma unroll 4
             for (int s = 0; s < S; ++s) acc += dT[s * L2 + j];
-            if (j < L) d_b_mu[j] += acc; else d_b_lv[j - L] += acc;
         }
+        if (i == t0) *dst0 = old0 + acc;
+        else { float* d = dst_of(i); *d += acc; }
     }
 }
 
