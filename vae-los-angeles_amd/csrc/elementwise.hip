@@ -745,14 +745,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWBatch batch, floa
         rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
     }
     const float step = lr / bc1;
-    for (long i = (long)lb * blockDim.x + threadIdx.x; i < it.n; i += (long)nb * blockDim.x) {
-        float g = it.g[i];
-        if (maximize) g = -g;
-        float p = it.p[i] * (1.f - lr * wd);
-        const float m = b1 * it.m[i] + (1.f - b1) * g;
-        const float v = b2 * it.v[i] + (1.f - b2) * g * g;
-        p -= step * m / (sqrtf(v) * rsqrt_bc2 + eps);
-        it.p[i] = p; it.m[i] = m; it.v[i] = v;
+    // U elements per thread are requested before any is updated: the stores of one element may alias the loads of the next as far
+    // as the compiler knows, so one element per iteration was a chain of 4-5 dependent round trips (14 us for 42 MB)
+    constexpr int U = 4;
+    const long stride = (long)nb * blockDim.x;
+    for (long i0 = (long)lb * blockDim.x + threadIdx.x; i0 < it.n; i0 += U * stride) {
+        float g[U], p[U], m[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = min(i0 + u * stride, (long)it.n - 1);
+            g[u] = it.g[i]; p[u] = it.p[i]; m[u] = it.m[i]; v[u] = it.v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride;
+            if (i >= it.n) break;
+            const float gg = maximize ? -g[u] : g[u];
+            float pp = p[u] * (1.f - lr * wd);
+            const float mm_ = b1 * m[u] + (1.f - b1) * gg;
+            const float vv = b2 * v[u] + (1.f - b2) * gg * gg;
+            pp -= step * mm_ / (sqrtf(vv) * rsqrt_bc2 + eps);
+            it.p[i] = pp; it.m[i] = mm_; it.v[i] = vv;
+        }
     }
     if (copies) ctr_advance(step_dev, L, gridDim.x, steps_done + 1);
 }

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupReduc
     for (int j = 1; j < MMVAE_TN_GROUP_MAX; ++j) if (j < g.n && i >= g.first[j]) pi = j;
     const int e = i - g.first[pi], nk = g.nk[pi], ns = g.nsplit[pi];
     const float* sl = g.slab[pi] + e;
-    g.dW[pi][e] += slab_sum<MM_REDUCE_U>(sl, nk, ns);                                   // lddw == K for these (contiguous gradient views)
+    const float old = g.dW[pi][e];                       // requested with the first slab loads, not behind the sum (one round trip fewer)
+    g.dW[pi][e] = old + slab_sum<MM_REDUCE_U>(sl, nk, ns);                                   // lddw == K for these (contiguous gradient views)
 }
 
 #ifdef MM_STAMP
@@ -525,9 +526,10 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const int z0 = blockIdx.y * TN_RG, z1 = min(nsplit, z0 + TN_RG);
     const bool single = gridDim.y == 1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (long)gridDim.x * blockDim.x) {
-        const float s = slab_sum<MM_REDUCE_U>(slab + z0 * nk + i, nk, z1 - z0);
         const long n = i / K, k = i - n * K;
-        if (single) dW[n * ldw + k] += s;
+        const float old = single ? dW[n * ldw + k] : 0.f;   // requested with the first slab loads, not behind the sum (one round trip fewer)
+        const float s = slab_sum<MM_REDUCE_U>(slab + z0 * nk + i, nk, z1 - z0);
+        if (single) dW[n * ldw + k] = old + s;
         else unsafeAtomicAdd(dW + n * ldw + k, s);
     }
 }
